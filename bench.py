@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Headline benchmark: paired-samples/sec of the img+jnt assoc-VAE train step on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4|c1] [--no-cpu-baseline]
+
+A "step" is one pass of the hot path (input staging, forward, fused losses, backward,
+[gradient all-reduce], Adam + shadow refresh) over one batch of synthetic paired samples that is
+already resident in HBM.  Default workload = BASELINE.json configs[1] ("C2": 784-500-500 /
+147-200-200, n_z=20, batch 256 per GPU, bf16 operands); under torchrun every rank runs the same
+per-GPU batch (weak scaling) with one RCCL SUM all-reduce of the flat gradient per step.
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant
+kernel, measured with HIP events on the launch stream in a separate eager pass right after the
+timed region) and `cpu_baseline` (the NumPy oracle timed on this box's host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
+MFMA_F32_PEAK_TF = 157.3
+
+
+def arch(scope, n_in, hs, n_z):
+    return dict(scope=scope, hidden_conv=False, n_hidden_recog_1=hs[0], n_hidden_recog_2=hs[min(1, len(hs) - 1)],
+                n_hidden_gener_1=hs[0], n_hidden_gener_2=hs[min(1, len(hs) - 1)], n_input=n_in, n_z=n_z,
+                n_hidden=list(hs))
+
+
+CONFIGS = {
+    # name: (archs, per-GPU batch, compute dtype, label)
+    "c1": ([arch("image", 784, [500, 500], 20), arch("joint", 147, [200, 200], 20)], 100, "bf16",
+           "C1 img+jnt assoc-VAE 784-500-500/147-200-200 n_z=20 batch=100"),
+    "c2": ([arch("image", 784, [500, 500], 20), arch("joint", 147, [200, 200], 20)], 256, "bf16",
+           "C2 img+jnt assoc-VAE 784-500-500/147-200-200 n_z=20 batch=256/GPU bf16"),
+    "c4": ([arch("image", 784, [1024] * 4, 64), arch("joint", 147, [1024] * 4, 64)], 4096, "bf16",
+           "C4 4x1024 MLP enc/dec n_z=64 batch=4096 bf16 (MFMA stress)"),
+}
+HYPER = dict(binary=[True, False], weights=[50.0, 1.0], assoc_lambda=8.0, learning_rate=1e-3)   # script values
+
+
+def synth(rng, rows):
+    """SURVEY.md 8d synthetic inputs: stroke-like images in [0,1] (70 % dark), z-scored joint features."""
+    img = (np.clip(rng.beta(0.25, 1.5, size=(rows, 784)), 0, 1) * (rng.random((rows, 784)) >= 0.7)).astype(np.float32)
+    jnt = rng.standard_normal((rows, 147)).astype(np.float32)
+    return img, jnt
+
+
+def dense_layers(na):
+    hs, n_in, nz = na["n_hidden"], na["n_input"], na["n_z"]
+    enc, prev = [], n_in
+    for h in hs:
+        enc.append((prev, h)); prev = h
+    head = (prev, 2 * nz)
+    dec, prev = [], nz
+    for h in hs:
+        dec.append((prev, h)); prev = h
+    return enc, head, dec, (prev, n_in)
+
+
+def launch_work(archs, B, es):
+    """Algorithmic HBM bytes and FLOPs of every launch of one step (SURVEY.md 8d accounting:
+    operands read once, results written once, compute-dtype activations, fp32 grads/Adam)."""
+    out = {}
+
+    def add(name, by, fl):
+        b0, f0 = out.get(name, (0, 0))
+        out[name] = (b0 + by, f0 + fl)
+    P = 0
+    for na in archs:
+        enc, head, dec, outl = dense_layers(na)
+        L = len(enc)
+        nz, n_in = na["n_z"], na["n_input"]
+        for k, (i, o) in enumerate(enc):
+            add("fwd_enc%d" % (k + 1), (B * i + (i + 1) * o + B * o) * es, 2 * B * (i + 1) * o)
+        i, o = head
+        add("fwd_head", (B * i + (i + 1) * o) * es + B * o * 4 + B * nz * (4 + es), 2 * B * (i + 1) * o)
+        for k, (i, o) in enumerate(dec):
+            add("fwd_dec%d" % (k + 1), (B * i + (i + 1) * o + B * o) * es, 2 * B * (i + 1) * o)
+        add("fwd_dec1", 2 * B * 2 * nz * 4, 0)                                   # latent item: mulv in, g0 out
+        i, o = outl
+        add("fwd_out_loss", (B * i + (i + 1) * o + B * o) * es + B * o * 4, 2 * B * (i + 1) * o)
+
+        def bwd(name, i, o, dgrad=True):
+            by = (B * i + B * o) * es + (i + 1) * o * 4                          # wgrad: X, dA in; G out
+            fl = 2 * B * (i + 1) * o
+            if dgrad:
+                by += (B * o + i * o + 2 * B * i) * es
+                fl += 2 * B * i * o
+            add(name, by, fl)
+        bwd("bwd_out", *outl)
+        for k in range(L - 1, 0, -1):
+            bwd("bwd_dec%d" % (k + 1), *dec[k])
+        bwd("bwd_dec1_latent", *dec[0])
+        bwd("bwd_head", *head)
+        for k in range(L - 1, 0, -1):
+            bwd("bwd_enc%d" % (k + 1), *enc[k])
+        bwd("bwd_enc1", *enc[0], dgrad=False)
+        add("prep", B * n_in * (4 + 4 + es), 0)
+        P += sum((i + 1) * o for i, o in enc + dec + [head, outl])
+    add("adam", 7 * P * 4 + P * es, 0)
+    return out, P
+
+
+def cpu_baseline(archs, B, budget_s=12.0):
+    """The CPU oracle (NumPy fp32 restatement of vae_assoc.py, kind "port") timed on this box's
+    host cores on a bounded sample of the same workload."""
+    from oracle import vae_assoc_oracle as O
+    rng = np.random.default_rng(20260104)
+    img, jnt = synth(rng, B)
+    eps = rng.standard_normal((B, archs[0]["n_z"])).astype(np.float32)
+    m = O.OracleAssocVAE(archs, HYPER["binary"], "relu", HYPER["weights"], HYPER["assoc_lambda"], HYPER["learning_rate"], B,
+                         dtype=np.float32, seed=0)
+    m.partial_fit([img, jnt], eps)                # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        m.partial_fit([img, jnt], eps)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 2000:
+            break
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"value": round(n * B / dt, 1), "unit": "paired-samples/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps of batch %d (NumPy/OpenBLAS fp32 oracle of vae_assoc.py, %.1f s)" % (n, B, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--kernel-steps", type=int, default=200, help="steps of the per-kernel hipEvent pass")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    g.build()
+    from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    archs, B, dtype, label = CONFIGS[args.config]
+    dtype = args.dtype or dtype
+    es = 2 if dtype == "bf16" else 4
+    model = AssocVariationalAutoEncoder(archs, transfer_fct="relu", batch_size=B, compute_dtype=dtype, device=local_rank,
+                                        seed=0, use_graph=not args.no_graph, data_parallel=world > 1, **HYPER)
+    # resident synthetic data: 16 batches per rank (rank r owns global rows [r*B, (r+1)*B) of each global batch)
+    nb = 16
+    rng = np.random.default_rng(20260104 + rank)
+    img, jnt = synth(rng, nb * B)
+    data = torch.as_tensor(np.concatenate([img, jnt], axis=1)).cuda()           # [nb*B, 931], split by pointer + stride
+    batches = [[data[i * B:(i + 1) * B, :784], data[i * B:(i + 1) * B, 784:]] for i in range(nb)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.partial_fit(batches[i % nb], return_cost=False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.partial_fit(batches[i % nb], return_cost=False)                    # eps: in-kernel Philox stream
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    last_cost = float(model.cost_history(1)[0])
+
+    # ---- per-kernel device time: eager launches bracketed by hipEvents on the launch stream
+    kern = {}
+    if rank == 0:
+        L, h = model._L, model._h
+        L.avae_timing_enable(h, 1)
+        for i in range(args.kernel_steps):
+            model.partial_fit(batches[i % nb], return_cost=False)
+        buf = C.create_string_buffer(1 << 16)
+        L.avae_timing_report(h, buf, len(buf))
+        L.avae_timing_enable(h, 0)
+        for line in buf.value.decode().splitlines():
+            name, calls, avg_ms, min_ms = line.split()
+            kern[name] = (int(calls), float(avg_ms), float(min_ms))
+    if world > 1:
+        barrier()
+
+    if rank == 0:
+        work, P = launch_work(archs, B, es)
+        names = [n for n in kern if n in work]
+        dom = max(names, key=lambda n: kern[n][1]) if names else None
+        roof = None
+        if dom:
+            by, fl = work[dom]
+            avg_s = kern[dom][1] * 1e-3
+            t_hbm, t_mfma = by / (HBM_PEAK_GBS * 1e9), fl / ((MFMA_BF16_PEAK_TF if es == 2 else MFMA_F32_PEAK_TF) * 1e12)
+            if t_mfma > t_hbm:
+                peak = MFMA_BF16_PEAK_TF if es == 2 else MFMA_F32_PEAK_TF
+                ach = fl / avg_s / 1e12
+                roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+            else:
+                ach = by / avg_s / 1e9
+                roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+            roof.update({"traffic": None, "kernel": dom, "avg_us": round(kern[dom][1] * 1e3, 2),
+                         "algorithmic_bytes": by, "algorithmic_flop": fl})
+        step_bytes = sum(v[0] for v in work.values())
+        step_flop = sum(v[1] for v in work.values())
+        out = {
+            "metric": "paired-samples/sec (img+jnt assoc-VAE train step)",
+            "value": round(B * world * args.steps / dt, 1),
+            "unit": "paired-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": label, "global_batch": B * world, "per_gpu_batch": B, "n_params": P,
+                       "parallelism": "dp%d" % world, "graph": not args.no_graph},
+            "roofline": roof,
+            "step_roofline": {"algorithmic_bytes": step_bytes, "algorithmic_flop": step_flop,
+                              "hbm_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                              "mfma_frac": round(step_flop / (dt / args.steps) / 1e12 / (MFMA_BF16_PEAK_TF if es == 2 else MFMA_F32_PEAK_TF), 4)},
+            "kernels_us": {n: round(v[1] * 1e3, 2) for n, v in sorted(kern.items())},
+            "last_cost": last_cost,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(archs, B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+/*
+ * avae.h -- C ABI of libavae: the MI355X (gfx950) associative-VAE training path.
+ *
+ * This is the drop-in boundary of the repository.  The reference (navigator8972/vae_assoc) has
+ * no FFI of its own: its boundary is the Python class AssocVariationalAutoEncoder whose methods
+ * each end in one TensorFlow `sess.run` (reference vae_assoc.py:383,389,399-402,417-418,423-424).
+ * Every entry point below replaces one of those `sess.run` calls (cited per function); the
+ * Python class in vae_assoc_amd/vae_assoc.py keeps the reference's method surface and calls
+ * these through ctypes.
+ *
+ * Conventions
+ *  - plain C types only; device pointers are raw `float*` into HBM owned by the caller
+ *    (PyTorch-ROCm tensors are used purely as containers on the Python side);
+ *  - every function returns 0 on success, nonzero on failure; the message is available from
+ *    avae_last_error(); no C++ exception crosses the ABI;
+ *  - one handle = one model replica on one GPU; calls on one handle serialise on an internal
+ *    mutex (the reference's callers use the session from a worker thread and the GUI thread,
+ *    baxter_vae_assoc_writer.py:651-673); different handles are independent;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the library's own stream).  Work is
+ *    enqueued asynchronously; a call only synchronises when it has to hand a host value back
+ *    (a non-NULL `cost_host`, get/set of parameters, save/load);
+ *  - matrices are row-major; an input batch of modality m is [rows, n_input_m] float32 with a
+ *    row stride (leading dimension, in floats) given by `x_ld[m]` (NULL = dense, ld = n_input).
+ *
+ * Flat parameter order (avae_get_params / avae_set_params / avae_get_grads / Adam state) is the
+ * reference's variable-creation order, per modality (vae_assoc.py:185-215,257-300):
+ *   enc W1[n_in,H1] b1 W2[H1,H2] b2 ... Wmu[HL,n_z] bmu Wsig[HL,n_z] bsig
+ *   dec V1[n_z,H1] c1 V2[H1,H2] c2 ... Vout[HL,n_in] cout         each W row-major [in,out].
+ */
+#ifndef AVAE_H_
+#define AVAE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVAE_ABI_VERSION 1
+#define AVAE_MAX_MODALITIES 4
+#define AVAE_MAX_HIDDEN 8
+
+/* hidden-layer transfer function: reference `transfer_fct` (vae_assoc.py:26,48,502) */
+enum { AVAE_ACT_IDENTITY = 0, AVAE_ACT_RELU = 1, AVAE_ACT_SOFTPLUS = 2, AVAE_ACT_SIGMOID = 3, AVAE_ACT_TANH = 4 };
+/* arithmetic type of the GEMM operands (accumulation, losses, latent maths and Adam are fp32) */
+enum { AVAE_F32 = 0, AVAE_BF16 = 1 };
+
+typedef struct avae_modality {
+    int32_t n_input;                    /* reference network_architecture["n_input"] */
+    int32_t n_hidden_layers;            /* 2 in the reference (n_hidden_recog_1/2)   */
+    int32_t n_hidden[AVAE_MAX_HIDDEN];  /* encoder widths; the MLP decoder reuses them (vae_assoc.py:257,280,293) */
+    int32_t binary;                     /* 1: Bernoulli recon + sigmoid output (:321-324,:293-297); 0: Gaussian (:327-328,:299-303) */
+    float weight;                       /* reference `weights[m]` (:319,:340) */
+    int32_t hidden_conv;                /* must be 0 (MLP branch); conv/deconv branch is a later round */
+    int32_t reserved;
+} avae_modality;
+
+typedef struct avae_config {
+    int32_t abi_version;                /* AVAE_ABI_VERSION */
+    int32_t n_modalities;
+    avae_modality mod[AVAE_MAX_MODALITIES];
+    int32_t n_z;                        /* taken from modality 0 in the reference (:89) */
+    int32_t batch_size;                 /* rows per train/eval step on THIS replica (reference batch_size, :27,:90) */
+    int32_t batch_global;               /* divisor of the mean terms; 0 -> batch_size.  world_size*batch_size under data parallelism */
+    int32_t row_offset;                 /* global row index of local row 0 (rank*batch_size): keys the internal eps generator */
+    int32_t activation;                 /* AVAE_ACT_* */
+    int32_t compute_dtype;              /* AVAE_F32 | AVAE_BF16 */
+    int32_t device;                     /* HIP device ordinal */
+    int32_t use_graph;                  /* 1: replay the step as a captured hipGraph */
+    float assoc_lambda;                 /* reference assoc_lambda (:29,:369) */
+    float learning_rate;                /* reference learning_rate (:50,:374) */
+    float beta1, beta2, adam_eps;       /* TF-1 AdamOptimizer defaults 0.9 / 0.999 / 1e-8 when all three are 0 */
+    uint64_t seed;                      /* Philox key of the internal eps generator */
+    void* workspace;                    /* optional caller-owned device memory (>= avae_workspace_bytes); NULL -> hipMalloc */
+    size_t workspace_bytes;
+} avae_config;
+
+typedef struct avae_handle avae_handle;
+
+/* Size of the single device allocation a replica needs (parameters, Adam state, compute-dtype
+ * shadows, activations, gradients).  Lets the caller allocate it as a torch tensor. */
+int avae_workspace_bytes(const avae_config* cfg, size_t* bytes);
+
+/* Replaces AssocVariationalAutoEncoder.__init__ graph/session construction (vae_assoc.py:26-71).
+ * Parameters start at zero: call avae_set_params (weights are injected explicitly because the
+ * TF RNG stream of xavier_init, :11-18, cannot be reproduced). */
+int avae_create(const avae_config* cfg, avae_handle** out);
+void avae_destroy(avae_handle* h);
+/* h may be NULL: returns the message of the last failed avae_create on this thread. */
+const char* avae_last_error(const avae_handle* h);
+
+int avae_param_count(const avae_handle* h, size_t* n);
+int avae_get_params(avae_handle* h, float* host_dst);         /* flat order above, host memory */
+int avae_set_params(avae_handle* h, const float* host_src);
+int avae_get_grads(avae_handle* h, float* host_dst);          /* gradient of the last step, flat order (parity tests) */
+/* Adam slots + step counter: what tf.train.Saver checkpoints besides the weights (vae_assoc.py:70,427-463). */
+int avae_get_opt_state(avae_handle* h, float* host_m, float* host_v, int64_t* step);
+int avae_set_opt_state(avae_handle* h, const float* host_m, const float* host_v, int64_t step);
+
+/* partial_fit (vae_assoc.py:378-386): one sess.run((optimizer, cost)).
+ *   x_dev[m]  device [batch_size, n_input_m] float32, row stride x_ld[m]
+ *   eps_dev   device [batch_size, n_z] float32 shared by all modalities (:90), or NULL ->
+ *             internal Philox4x32-10 normals keyed by (seed, step, global row)
+ *   cost_host NULL -> fully asynchronous; else receives the cost of this step's forward pass
+ *             (pre-update weights, as in the reference) after a stream synchronise. */
+int avae_train_step(avae_handle* h, const float* const* x_dev, const int32_t* x_ld,
+                    const float* eps_dev, float* cost_host, void* stream);
+/* The same step cut at the data-parallel seam: backward leaves the local gradient (internal
+ * padded layout, pads zero) and, in the last float, the local cost in one contiguous device
+ * buffer -- SUM-all-reduce that buffer across replicas, then apply. */
+int avae_step_backward(avae_handle* h, const float* const* x_dev, const int32_t* x_ld,
+                       const float* eps_dev, void* stream);
+int avae_step_apply(avae_handle* h, float* cost_host, void* stream);
+int avae_grad_buffer(avae_handle* h, float** dev_ptr, size_t* n_floats);
+/* Costs of the most recent `n` applied steps (oldest first), without having synchronised per step. */
+int avae_cost_history(avae_handle* h, int32_t n, float* host_dst, int64_t* last_step);
+
+/* evaluate_cost (vae_assoc.py:388-391): forward + loss, no update. */
+int avae_eval_cost(avae_handle* h, const float* const* x_dev, const int32_t* x_ld,
+                   const float* eps_dev, float* cost_host, void* stream);
+/* transform (vae_assoc.py:393-403): posterior mean (and optionally log-variance) of modality m;
+ * any row count. */
+int avae_encode(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld, int32_t rows,
+                float* mu_dev, float* logvar_dev, void* stream);
+/* generate (vae_assoc.py:405-419): decoder of modality m on fed z [rows, n_z]; any row count. */
+int avae_decode(avae_handle* h, int32_t m, const float* z_dev, int32_t rows, float* xhat_dev, void* stream);
+/* reconstruct (vae_assoc.py:421-425): encode -> z = mu + exp(lv/2)*eps -> decode for modality m.
+ * eps_dev [rows, n_z] or NULL (internal generator, a fresh draw per call as in the reference). */
+int avae_reconstruct(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld, const float* eps_dev,
+                     int32_t rows, float* xhat_dev, void* stream);
+
+/* save_model / restore_model (vae_assoc.py:427-463): own flat file (config echo + params + Adam
+ * slots + step); TF .ckpt files cannot be read offline. */
+int avae_save(avae_handle* h, const char* path);
+int avae_load(avae_handle* h, const char* path);
+
+/* Introspection used by bench.py / tests. */
+int avae_synchronize(avae_handle* h);
+/* Average device time (ms) of the kernels of one class over the calls since the last reset,
+ * measured with hipEvents on the stream the kernels were launched on.  Only recorded while
+ * timing is enabled (it forces eager launches instead of graph replay). */
+int avae_timing_enable(avae_handle* h, int32_t on);
+int avae_timing_report(avae_handle* h, char* buf, size_t buf_bytes);
+/* Copies a named internal fp32 tensor to the host (tests): "mulv<m>" [batch,2*n_z], "eps" [batch,n_z]. */
+int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t max_floats, size_t* n_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVAE_H_ */

@@ -1,0 +1,99 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads, exports every symbol
+include/avae.h declares, sizes a workspace on the host, and refuses to run without a GPU
+(no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, make_arch
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as g
+    g.build()
+    from vae_assoc_amd import _capi
+    return _capi
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "avae.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(avae_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    L = capi.lib()
+    declared = header_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(L, name), "libavae.so does not export %s" % name
+    assert sorted(capi.SYMBOLS) == declared, "python binding and include/avae.h disagree"
+
+
+def _config(capi, n_z=20, B=100):
+    cfg = capi.Config()
+    cfg.abi_version = capi.AVAE_ABI_VERSION
+    cfg.n_modalities = 2
+    for m, (n_in, h) in enumerate(((784, 500), (147, 200))):
+        cfg.mod[m].n_input = n_in
+        cfg.mod[m].n_hidden_layers = 2
+        cfg.mod[m].n_hidden[0] = h
+        cfg.mod[m].n_hidden[1] = h
+        cfg.mod[m].binary = 1 - m
+        cfg.mod[m].weight = 1.0
+    cfg.n_z, cfg.batch_size, cfg.activation, cfg.compute_dtype = n_z, B, 1, 1
+    cfg.learning_rate, cfg.assoc_lambda = 1e-3, 1.0
+    return cfg
+
+
+def test_workspace_size_is_host_only_and_sane(capi):
+    L = capi.lib()
+    n = C.c_size_t(0)
+    assert L.avae_workspace_bytes(C.byref(_config(capi)), C.byref(n)) == 0
+    P = 1468611
+    assert 4 * 4 * P < n.value < 64 * 4 * P          # theta, m, v, g + shadows + activations
+    cfg = _config(capi)
+    cfg.compute_dtype = 0
+    n32 = C.c_size_t(0)
+    assert L.avae_workspace_bytes(C.byref(cfg), C.byref(n32)) == 0 and n32.value > n.value
+
+
+def test_bad_configs_are_rejected_with_a_message(capi):
+    L = capi.lib()
+    n = C.c_size_t(0)
+    for mutate, needle in ((lambda c: setattr(c, "abi_version", 99), "abi_version"),
+                           (lambda c: setattr(c, "n_z", 65), "n_z"),
+                           (lambda c: setattr(c, "batch_size", 0), "batch_size"),
+                           (lambda c: setattr(c.mod[0], "hidden_conv", 1), "hidden_conv"),
+                           (lambda c: setattr(c, "n_modalities", 5), "n_modalities")):
+        cfg = _config(capi)
+        mutate(cfg)
+        assert L.avae_workspace_bytes(C.byref(cfg), C.byref(n)) != 0
+        assert needle in L.avae_last_error(None).decode()
+
+
+def test_no_cpu_fallback(capi):
+    """Without a HIP device avae_create must fail loudly, and so must the Python model."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the -m gpu suite")
+    L = capi.lib()
+    h = C.c_void_p()
+    assert L.avae_create(C.byref(_config(capi)), C.byref(h)) != 0
+    assert not h.value
+    assert L.avae_last_error(None)
+    from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+    with pytest.raises(RuntimeError):
+        AssocVariationalAutoEncoder([make_arch("image", 784, 500, 500, 20)], batch_size=8)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "vae_assoc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f

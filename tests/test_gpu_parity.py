@@ -1,0 +1,511 @@
+"""Parity of the HIP path (through the C ABI, include/avae.h) with the CPU oracle on a real MI355X.
+
+Tolerances (the oracle is fp64):
+  fp32 path : mu / lv / x_hat / cost <= 1e-5 relative, gradients <= 1e-4 of the tensor's max
+  bf16 path : cost <= 1e-3 relative (north_star), mu / lv <= 2e-2 absolute
+PARITY UNPINNED against the reference itself (it cannot run; see oracle/vae_assoc_oracle.py).
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_arch, synth_batch
+from oracle import vae_assoc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def V():
+    import __graft_entry__ as g
+    g.build()
+    from vae_assoc_amd import vae_assoc
+    assert torch.cuda.is_available()
+    return vae_assoc
+
+
+def per_tensor_err(archs, got, ref):
+    """max |got-ref| / max |ref| per named parameter tensor (flat layout)."""
+    out, off = [], 0
+    for m, na in enumerate(archs):
+        for name, shp in O.layer_shapes(na):
+            n = int(np.prod(shp))
+            a, b = got[off:off + n], ref[off:off + n]
+            out.append(("m%d.%s" % (m, name), float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))))
+            off += n
+    return out
+
+
+def build_pair(V, archs, binary, weights, lam, act, B, dtype, lr=1e-3, p0=None, seed=5, **kw):
+    model = V.AssocVariationalAutoEncoder(archs, binary=binary, transfer_fct=act, weights=weights, assoc_lambda=lam,
+                                          learning_rate=lr, batch_size=B, compute_dtype=dtype, seed=seed, **kw)
+    if p0 is None:
+        rng = np.random.default_rng(seed)
+        p0 = model.get_params()
+        off = 0
+        for na in archs:                       # non-zero biases: exercise the folded-bias column
+            for name, shp in O.layer_shapes(na):
+                n = int(np.prod(shp))
+                if len(shp) == 1:
+                    p0[off:off + n] = 0.05 * rng.standard_normal(n)
+                off += n
+    model.set_params(p0)
+    assert np.array_equal(model.get_params(), p0.astype(np.float32))         # set/get round trip is exact
+    ref = O.OracleAssocVAE(archs, binary, act, weights, lam, lr, B, params_flat=np.asarray(p0, dtype=np.float64))
+    return model, ref
+
+
+def check_step_parity(V, archs, binary, weights, lam, act, B, dtype, steps=3, seed=5, **kw):
+    fp32 = dtype == "fp32"
+    rng = np.random.default_rng(seed + 100)
+    nz = archs[0]["n_z"]
+    X = synth_batch(rng, B, [a["n_input"] for a in archs], binary if isinstance(binary, list) else [binary] * len(archs))
+    eps = rng.standard_normal((steps, B, nz)).astype(np.float32)
+    model, ref = build_pair(V, archs, binary, weights, lam, act, B, dtype, seed=seed, **kw)
+    # -- encoder outputs
+    mus = model.transform(X)
+    rmu = ref.transform(X)
+    for m in range(len(archs)):
+        err = np.abs(mus[m] - rmu[m]).max()
+        tol = 1e-5 * max(1.0, np.abs(rmu[m]).max()) if fp32 else 2e-2
+        assert err <= tol, "mu[%d] err %.3e > %.1e" % (m, err, tol)
+    # -- evaluate_cost does not change anything
+    p_before = model.get_params()
+    c_eval = model.evaluate_cost(X, eps[0])
+    r_eval = ref.evaluate_cost(X, eps[0])
+    tol_c = 1e-5 if fp32 else 1e-3
+    assert abs(c_eval - r_eval) <= tol_c * abs(r_eval), "evaluate_cost %.6f vs %.6f" % (c_eval, r_eval)
+    assert np.array_equal(model.get_params(), p_before)
+    # -- training steps: cost of the pre-update forward pass, gradients, Adam
+    for s in range(steps):
+        c_ref, g_ref, fw = ref.cost_and_grads(X, eps[s])
+        ref.apply_gradients(g_ref)
+        c = model.partial_fit(X, eps[s])
+        assert abs(c - c_ref) <= tol_c * abs(c_ref), "step %d cost %.6f vs oracle %.6f (rel %.2e)" % (
+            s, c, c_ref, abs(c - c_ref) / abs(c_ref))
+        if s == 0:
+            g = model.get_grads()
+            errs = per_tensor_err(archs, g, g_ref)
+            gtol = 1e-4 if fp32 else 6e-2
+            bad = [(n, e) for n, e in errs if e > gtol]
+            assert not bad, "gradient mismatch (rel to tensor max): %s" % bad
+            for m in range(len(archs)):          # mu / lv of the training forward pass
+                mulv = np.empty(B * 2 * nz, dtype=np.float32)
+                n = torch.zeros(1)
+                import ctypes as C
+                cnt = C.c_size_t(0)
+                rc = model._L.avae_debug_fetch(model._h, ("mulv%d" % m).encode(), mulv.ctypes.data_as(C.c_void_p),
+                                               mulv.size, C.byref(cnt))
+                assert rc == 0
+                mulv = mulv.reshape(B, 2 * nz)
+                tol = 1e-5 * max(1.0, np.abs(fw[m]["lv"]).max(), np.abs(fw[m]["mu"]).max()) if fp32 else 2e-2
+                assert np.abs(mulv[:, :nz] - fw[m]["mu"]).max() <= tol
+                assert np.abs(mulv[:, nz:] - fw[m]["lv"]).max() <= tol
+    dp = np.abs(model.get_params() - ref.get_params()).max()
+    # after k Adam steps every weight has moved <= k*lr; fp32 must track the oracle far inside that
+    assert dp <= (2e-5 if fp32 else 2.5 * steps * 1e-3), "params drift %.3e" % dp
+    return model, ref, X, eps
+
+
+# ----------------------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("name", ["script_nz4_b64", "c1_nz20_b100"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_golden_fixture(V, golden, name, dtype):
+    G = golden[name]
+    c = G["config"]
+    fp32 = dtype == "fp32"
+    M = len(c["archs"])
+    X = [G["x%d" % m] for m in range(M)]
+    model = V.AssocVariationalAutoEncoder(c["archs"], binary=c["binary"], transfer_fct=c["act"], weights=c["weights"],
+                                          assoc_lambda=c["assoc_lambda"], learning_rate=c["lr"], batch_size=c["B"],
+                                          compute_dtype=dtype)
+    model.set_params(G["params0"])
+    mus = model.transform(X)
+    for m in range(M):
+        assert np.abs(mus[m] - G["mu%d" % m]).max() <= (1e-5 * max(1, np.abs(G["mu%d" % m]).max()) if fp32 else 2e-2)
+    tol_c = 1e-5 if fp32 else 1e-3
+    costs = []
+    for s in range(3):
+        costs.append(model.partial_fit(X, G["eps"][s]))
+        if s == 0:
+            errs = per_tensor_err(c["archs"], model.get_grads(), G["grads0"].astype(np.float64))
+            bad = [(n, e) for n, e in errs if e > (1e-4 if fp32 else 6e-2)]
+            assert not bad, bad
+            if fp32:
+                assert np.abs(model.get_params() - G["params1"]).max() <= 2e-6
+    assert np.allclose(costs, G["costs"], rtol=tol_c, atol=0), (costs, G["costs"])
+    assert np.abs(model.get_params() - G["params3"]).max() <= (1e-5 if fp32 else 7.5e-3)
+    assert np.allclose(model.cost_history(3), costs, rtol=1e-6)
+    m_, v_, step = model.get_opt_state()
+    assert step == 3
+    if fp32:
+        assert abs(np.linalg.norm(m_.astype(np.float64)) - G["adam_m3_norm"]) <= 1e-4 * G["adam_m3_norm"]
+        assert abs(np.linalg.norm(v_.astype(np.float64)) - G["adam_v3_norm"]) <= 1e-4 * G["adam_v3_norm"]
+    # inference surface on the trained weights (fp32: weights equal the oracle's to ~1e-6)
+    if fp32:
+        t = model.transform(X)
+        gen = model.generate(G["eps"][1])
+        rec = model.reconstruct(X, eps=[G["eps"][1], G["eps"][2]])
+        for m in range(M):
+            assert np.abs(t[m] - G["t_mu%d" % m]).max() <= 1e-4
+            assert np.abs(gen[m][:16] - G["gen%d" % m]).max() <= 1e-4
+            assert np.abs(rec[m][:16] - G["rec%d" % m]).max() <= 1e-4
+        ce = model.evaluate_cost(X, G["eps"][2])
+        assert abs(ce - G["eval_cost3"]) <= 1e-4 * abs(G["eval_cost3"])
+
+
+# ----------------------------------------------------------------------------- full reference sizes
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_reference_default_architecture(V, dtype):
+    """784-500-500 / 147-200-200 (vae_assoc_ujichar_img_jnt.py:53-71), n_z=20, B=100 (BASELINE C1)."""
+    archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
+    check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", 100, dtype)
+
+
+def test_bench_config_c2_bf16(V):
+    """BASELINE C2: same nets, n_z=20, B=256, bf16."""
+    archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
+    check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", 256, "bf16")
+
+
+# ----------------------------------------------------------------------------- shapes / options
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [
+    dict(archs=[make_arch("a", 60, 20, 16, 5), make_arch("b", 21, 12, 10, 5)], binary=[True, False], w=[50.0, 1.0], lam=8.0, act="relu", B=9),
+    dict(archs=[make_arch("a", 60, 20, 16, 3), make_arch("b", 21, 12, 10, 3), make_arch("c", 256, 40, 40, 3)],
+         binary=[True, False, False], w=[2.0, 1.0, 0.5], lam=0.7, act="softplus", B=37),
+    dict(archs=[make_arch("a", 130, 0, 0, 4, n_hidden=[70, 65, 33]), make_arch("b", 11, 0, 0, 4, n_hidden=[7])],
+         binary=[False, True], w=[1.0, 3.0], lam=1e-2, act="tanh", B=64),
+    dict(archs=[make_arch("solo", 25, 9, 7, 1)], binary=True, w=1.0, lam=3.0, act="sigmoid", B=130),
+    dict(archs=[make_arch("a", 200, 0, 0, 64, n_hidden=[96]), make_arch("b", 70, 0, 0, 64, n_hidden=[80, 72])],
+         binary=[True, False], w=[1.0, 1.0], lam=0.05, act="relu", B=200),          # n_z=64: 128x128 head tile
+    dict(archs=[make_arch("a", 40, 24, 24, 6), make_arch("b", 30, 24, 24, 6), make_arch("c", 20, 16, 16, 6), make_arch("d", 10, 8, 8, 6)],
+         binary=[True, False, True, False], w=[1.0, 2.0, 3.0, 4.0], lam=0.3, act="identity", B=33),
+])
+def test_shapes_and_options(V, case, dtype):
+    check_step_parity(V, case["archs"], case["binary"], case["w"], case["lam"], case["act"], case["B"], dtype)
+
+
+def test_large_tile_path_fp32(V):
+    """Wide layers and a large batch select the 128x128 tile configuration."""
+    archs = [make_arch("a", 784, 0, 0, 32, n_hidden=[512, 384]), make_arch("b", 147, 0, 0, 32, n_hidden=[384, 256])]
+    check_step_parity(V, archs, [True, False], [5.0, 1.0], 0.5, "relu", 2048, "fp32", steps=2)
+
+
+def test_graph_replay_equals_eager(V):
+    archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
+    rng = np.random.default_rng(3)
+    X = synth_batch(rng, 256, [784, 147], [True, False])
+    eps = rng.standard_normal((4, 256, 20)).astype(np.float32)
+    res = []
+    for use_graph in (True, False):
+        m = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="relu", weights=[50, 1], assoc_lambda=8.0,
+                                          batch_size=256, compute_dtype="bf16", seed=1, use_graph=use_graph)
+        costs = [m.partial_fit(X, eps[s]) for s in range(4)]
+        res.append((costs, m.get_params()))
+    assert res[0][0] == res[1][0], "graph and eager costs differ (kernels are deterministic)"
+    assert np.array_equal(res[0][1], res[1][1])
+
+
+# ----------------------------------------------------------------------------- inference surface
+def test_transform_generate_reconstruct_rows(V):
+    archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
+    B = 64
+    model, ref = build_pair(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", B, "fp32")
+    rng = np.random.default_rng(8)
+    for rows in (1, 7, 64, 65, 150):               # below, at and above batch_size (chunked), ragged tail
+        X = synth_batch(rng, rows, [784, 147], [True, False])
+        mus, rmu = model.transform(X), ref.transform(X)
+        one = model.transform(X[1], sens_idx=1)
+        assert np.abs(one - rmu[1]).max() <= 1e-5 * max(1, np.abs(rmu[1]).max())
+        z = rng.standard_normal((rows, 20)).astype(np.float32)
+        gen, rgen = model.generate(z), ref.generate(z)
+        e = [rng.standard_normal((rows, 20)).astype(np.float32) for _ in range(2)]
+        rec, rrec = model.reconstruct(X, eps=e), ref.reconstruct(X, eps=e)
+        for m in range(2):
+            assert mus[m].shape == (rows, 20) and gen[m].shape == (rows, archs[m]["n_input"])
+            assert np.abs(mus[m] - rmu[m]).max() <= 1e-5 * max(1, np.abs(rmu[m]).max())
+            assert np.abs(gen[m] - rgen[m]).max() <= 1e-5 * max(1, np.abs(rgen[m]).max())
+            assert np.abs(rec[m] - rrec[m]).max() <= 1e-5 * max(1, np.abs(rrec[m]).max())
+    # empty input
+    assert model.transform(np.zeros((0, 147), np.float32), sens_idx=1).shape == (0, 20)
+    # torch tensors in -> torch tensors out, on the device
+    xt = torch.as_tensor(X[0]).cuda()
+    out = model.transform(xt, sens_idx=0)
+    assert torch.is_tensor(out) and out.is_cuda
+    # generate() with no argument draws batch_size rows from numpy's RNG (vae_assoc.py:412-414)
+    np.random.seed(0)
+    g0 = model.generate()
+    np.random.seed(0)
+    zz = np.random.normal(size=(B, 20))
+    assert g0[0].shape == (B, 784) and np.abs(g0[1] - ref.generate(zz)[1]).max() <= 1e-4
+    # cross-modal inference pattern of the reference's callers (baxter_vae_assoc_writer.py:426-432)
+    z_rep = model.transform([X[0], np.zeros_like(X[1])])
+    jnt = model.generate(z_mu=z_rep[0])[1]
+    assert np.abs(jnt - ref.generate(ref.transform([X[0], np.zeros_like(X[1])])[0])[1]).max() <= 1e-4
+    # training right after inference still matches (inference must not disturb the zero padding)
+    Xb = synth_batch(rng, B, [784, 147], [True, False])
+    eb = rng.standard_normal((B, 20)).astype(np.float32)
+    c, cr = model.partial_fit(Xb, eb), ref.partial_fit(Xb, eb)
+    assert abs(c - cr) <= 1e-5 * abs(cr)
+    assert np.abs(model.get_params() - ref.get_params()).max() <= 2e-6
+
+
+def test_strided_modalities_from_one_matrix(V):
+    """train() hands column slices of one [B, 931] matrix (vae_assoc.py:510,543): no copies."""
+    archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
+    B = 50
+    model, ref = build_pair(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", B, "fp32")
+    rng = np.random.default_rng(1)
+    X = synth_batch(rng, B, [784, 147], [True, False])
+    eps = rng.standard_normal((B, 20)).astype(np.float32)
+    big = torch.as_tensor(np.concatenate(X, axis=1)).cuda()
+    c = model.partial_fit([big[:, :784], big[:, 784:]], eps)
+    cr = ref.partial_fit(X, eps)
+    assert abs(c - cr) <= 1e-5 * abs(cr)
+
+
+def test_wrong_shapes_raise(V):
+    archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
+    model, _ = build_pair(V, archs, [True, False], 1.0, 1.0, "relu", 16, "bf16")
+    with pytest.raises(ValueError):
+        model.partial_fit([np.zeros((15, 784), np.float32), np.zeros((15, 147), np.float32)])
+    with pytest.raises(ValueError):
+        model.transform(np.zeros((4, 100), np.float32), sens_idx=0)
+    with pytest.raises(NotImplementedError):
+        V.AssocVariationalAutoEncoder([dict(archs[0], hidden_conv=True)], batch_size=4)
+    with pytest.raises(ValueError):
+        V.AssocVariationalAutoEncoder([archs[0], dict(archs[1], n_z=7)], batch_size=4)
+
+
+# ----------------------------------------------------------------------------- internal eps stream
+def philox4x32_10(c, k):
+    c = [np.uint32(x) for x in c]
+    k = [np.uint32(x) for x in k]
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * np.uint64(c[0])
+        p1 = np.uint64(0xCD9E8D57) * np.uint64(c[2])
+        c = [np.uint32(p1 >> np.uint64(32)) ^ c[1] ^ k[0], np.uint32(p1 & np.uint64(0xFFFFFFFF)),
+             np.uint32(p0 >> np.uint64(32)) ^ c[3] ^ k[1], np.uint32(p0 & np.uint64(0xFFFFFFFF))]
+        k = [np.uint32((int(k[0]) + 0x9E3779B9) & 0xFFFFFFFF), np.uint32((int(k[1]) + 0xBB67AE85) & 0xFFFFFFFF)]
+    return [int(x) for x in c]
+
+
+def fetch(model, name, shape):
+    import ctypes as C
+    buf = np.empty(int(np.prod(shape)), dtype=np.float32)
+    cnt = C.c_size_t(0)
+    assert model._L.avae_debug_fetch(model._h, name.encode(), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(cnt)) == 0
+    return buf[:cnt.value].reshape(shape)
+
+
+def test_internal_eps_is_philox_normal_and_shard_consistent(V):
+    archs = [make_arch("image", 784, 32, 24, 20), make_arch("joint", 147, 24, 16, 20)]
+    B = 512
+    rng = np.random.default_rng(0)
+    X = synth_batch(rng, B, [784, 147], [True, False])
+    m = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="relu", batch_size=B, compute_dtype="bf16", seed=77)
+    m.partial_fit(X)                              # eps=None -> internal stream, step 0
+    e0 = fetch(m, "eps", (B, 20)).copy()
+    m.partial_fit(X)
+    e1 = fetch(m, "eps", (B, 20)).copy()
+    assert abs(e0.mean()) < 0.05 and abs(e0.std() - 1) < 0.05 and not np.array_equal(e0, e1)
+    # documented generator: counter (global row, dim quad, step lo, step hi ^ salt), key = seed; Box-Muller
+    salt = 0x7261696E
+    for (row, q) in ((0, 0), (5, 3), (511, 4)):
+        r = philox4x32_10([row, q, 0, salt & 0xFFFFFFFF], [77, 0])
+        u = [((x >> 8) + 0.5) / 16777216.0 for x in r]
+        want = [np.sqrt(-2 * np.log(u[0])) * np.cos(2 * np.pi * u[1]), np.sqrt(-2 * np.log(u[0])) * np.sin(2 * np.pi * u[1]),
+                np.sqrt(-2 * np.log(u[2])) * np.cos(2 * np.pi * u[3]), np.sqrt(-2 * np.log(u[2])) * np.sin(2 * np.pi * u[3])]
+        assert np.allclose(e0[row, 4 * q:4 * q + 4], want, atol=2e-4), (row, q, e0[row, 4 * q:4 * q + 4], want)
+    # a replica that owns global rows [256, 512) draws the same numbers for them (data-parallel consistency)
+    from vae_assoc_amd import _capi
+    half = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="relu", batch_size=256, compute_dtype="bf16", seed=77)
+    half._L.avae_destroy(half._h)
+    half._cfg.row_offset = 256
+    half._cfg.batch_global = 512
+    import ctypes as C
+    h = C.c_void_p()
+    _capi.check(None, half._L.avae_create(C.byref(half._cfg), C.byref(h)), "avae_create")
+    half._h = h
+    half.set_params(m.get_params())
+    half.partial_fit([x[256:] for x in X], return_cost=False)
+    assert np.array_equal(fetch(half, "eps", (256, 20)), e0[256:])
+
+
+# ----------------------------------------------------------------------------- data-parallel property on one GPU
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_two_shard_replicas_sum_to_global_batch(V, dtype):
+    """Size-independent property at the BENCH size: two replicas with B_loc=256, B_global=512 (built
+    through the C ABI with row_offset / batch_global) produce gradients whose SUM equals the
+    single-replica B=512 gradient -- the data-parallel contract of SURVEY.md 8e."""
+    import ctypes as C
+    from vae_assoc_amd import _capi
+    archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
+    rng = np.random.default_rng(12)
+    X = synth_batch(rng, 512, [784, 147], [True, False])
+    eps = rng.standard_normal((512, 20)).astype(np.float32)
+    kw = dict(binary=[True, False], transfer_fct="relu", weights=[50, 1], assoc_lambda=8.0, compute_dtype=dtype, seed=2)
+    full = V.AssocVariationalAutoEncoder(archs, batch_size=512, **kw)
+    p0 = full.get_params()
+    full._backward(X, eps)
+    g_full = full._grad_tensor().clone()
+    gsum = torch.zeros_like(g_full)
+    for r in range(2):
+        rep = V.AssocVariationalAutoEncoder(archs, batch_size=256, **kw)
+        rep._L.avae_destroy(rep._h)
+        rep._cfg.row_offset, rep._cfg.batch_global = 256 * r, 512
+        h = C.c_void_p()
+        _capi.check(None, rep._L.avae_create(C.byref(rep._cfg), C.byref(h)), "avae_create")
+        rep._h = h
+        rep.set_params(p0)
+        rep._backward([x[256 * r:256 * (r + 1)] for x in X], eps[256 * r:256 * (r + 1)])
+        assert rep._grad_tensor().shape == g_full.shape
+        gsum += rep._grad_tensor()
+    torch.cuda.synchronize()
+    gf, gs = g_full.cpu().numpy().astype(np.float64), gsum.cpu().numpy().astype(np.float64)
+    cost_full, cost_sum = gf[-1], gs[-1]
+    assert abs(cost_full - cost_sum) <= 1e-5 * abs(cost_full)
+    # gradients agree to accumulation-order rounding (K = 512 in one product vs 256 + 256)
+    assert np.abs(gf[:-1] - gs[:-1]).max() <= (2e-5 if dtype == "fp32" else 2e-3) * np.abs(gf[:-1]).max()
+
+
+# ----------------------------------------------------------------------------- checkpoint, history, train()
+def test_save_restore_roundtrip(V, tmp_path, capsys):
+    archs = [make_arch("image", 784, 32, 24, 4), make_arch("joint", 147, 24, 16, 4)]
+    B = 32
+    rng = np.random.default_rng(4)
+    X = synth_batch(rng, B, [784, 147], [True, False])
+    eps = rng.standard_normal((4, B, 4)).astype(np.float32)
+    a, _ = build_pair(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", B, "fp32")
+    for s in range(2):
+        a.partial_fit(X, eps[s])
+    folder = str(tmp_path)
+    a.save_model(os.path.join(folder, "m.ckpt"))
+    b, _ = build_pair(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", B, "fp32", seed=99)
+    b.restore_model(folder=folder)                       # newest *.ckpt in the folder
+    assert np.array_equal(a.get_params(), b.get_params())
+    ma, va, sa = a.get_opt_state()
+    mb, vb, sb = b.get_opt_state()
+    assert sa == sb == 2 and np.array_equal(ma, mb) and np.array_equal(va, vb)
+    ca = [a.partial_fit(X, eps[s]) for s in (2, 3)]
+    cb = [b.partial_fit(X, eps[s]) for s in (2, 3)]
+    assert ca == cb and np.array_equal(a.get_params(), b.get_params())      # resume is exact
+    # reference behaviour: failures print and return, they do not raise (vae_assoc.py:448,459,462)
+    b.restore_model(folder=os.path.join(folder, "nope"))
+    b.restore_model(folder=folder, fname="missing.ckpt")
+    (tmp_path / "bad.ckpt").write_bytes(b"not a checkpoint")
+    b.restore_model(folder=folder, fname="bad.ckpt")
+    out = capsys.readouterr().out
+    assert "Invalid or non-exist model folder." in out and out.count("Invalid or non-exist model file.") >= 2
+    c = V.AssocVariationalAutoEncoder([make_arch("image", 784, 16, 8, 4)], batch_size=B, compute_dtype="fp32")
+    c.restore_model(folder=folder, fname="m.ckpt")       # architecture mismatch: printed, not raised
+    assert "mismatch" in capsys.readouterr().out
+
+
+def test_train_loop_matches_oracle_loop(V):
+    """train() (vae_assoc.py:498-583): same data order, same explicit eps => same avg_cost_hist."""
+    from vae_assoc_amd import dataset
+    archs = [make_arch("image", 784, 32, 24, 4), make_arch("joint", 147, 24, 16, 4)]
+    rng = np.random.default_rng(6)
+    N, B = 300, 32
+    data = np.concatenate(synth_batch(rng, N, [784, 147], [True, False]), axis=1)
+    eps_all = rng.standard_normal((64, B, 4)).astype(np.float32)
+    results = []
+    for which in ("hip", "oracle"):
+        np.random.seed(42)
+        ds = dataset.construct_datasets(data.copy())
+        if which == "hip":
+            # explicit eps through partial_fit: wrap the model class so train() feeds it
+            class Fed(V.AssocVariationalAutoEncoder):
+                _k = 0
+
+                def partial_fit(self, X, eps=None, return_cost=True):
+                    e = eps_all[Fed._k]
+                    Fed._k += 1
+                    return super().partial_fit(X, e, return_cost)
+            orig = V.AssocVariationalAutoEncoder
+            V.AssocVariationalAutoEncoder = Fed
+            try:
+                model, hist = V.train(ds, archs, binary=[True, False], weights=[50.0, 1.0], assoc_lambda=8.0, batch_size=B,
+                                      training_epochs=3, display_step=10, compute_dtype="fp32", seed=8)
+            finally:
+                V.AssocVariationalAutoEncoder = orig
+            p0 = None
+            results.append((hist, model.get_params()))
+        else:
+            p_init = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="relu", batch_size=B,
+                                                   compute_dtype="fp32", seed=8).get_params()
+            model, hist = O.train(ds, archs, binary=[True, False], weights=[50.0, 1.0], assoc_lambda=8.0, batch_size=B,
+                                  training_epochs=3, params_flat=p_init.astype(np.float64), eps_fn=lambda s: eps_all[s])
+            results.append((hist, model.get_params()))
+    (h_hip, p_hip), (h_ref, p_ref) = results
+    assert len(h_hip) == len(h_ref) == 3 * (240 // B)
+    assert np.allclose(h_hip, h_ref, rtol=2e-5)
+    assert np.abs(p_hip - p_ref).max() <= 5e-5
+
+
+def test_early_stop_runs(V, capsys):
+    from vae_assoc_amd import dataset
+    archs = [make_arch("image", 784, 16, 12, 4), make_arch("joint", 147, 12, 8, 4)]
+    rng = np.random.default_rng(6)
+    data = np.concatenate(synth_batch(rng, 200, [784, 147], [True, False]), axis=1)
+    np.random.seed(1)
+    ds = dataset.construct_datasets(data)
+    model, hist = V.train(ds, archs, binary=[True, False], batch_size=10, training_epochs=4, early_stop=2, display_step=1)
+    assert "Validation cost=" in capsys.readouterr().out and len(hist) >= 16 and np.all(np.isfinite(hist))
+
+
+def test_concurrent_callers_serialise(V):
+    """The reference's callers hit one session from a worker thread and the GUI thread
+    (baxter_vae_assoc_writer.py:651-673): calls on one handle must serialise, not corrupt."""
+    archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
+    model, ref = build_pair(V, archs, [True, False], 1.0, 1.0, "relu", 64, "fp32")
+    rng = np.random.default_rng(0)
+    zs = [rng.standard_normal((64, 20)).astype(np.float32) for _ in range(4)]
+    want = [ref.generate(z) for z in zs]
+    errs = []
+
+    def worker(i):
+        try:
+            for _ in range(10):
+                out = model.generate(zs[i])
+                for m in range(2):
+                    if np.abs(out[m] - want[i][m]).max() > 1e-4:
+                        errs.append((i, m))
+        except Exception as e:      # noqa
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+
+
+def test_determinism_and_stress_config_c4(V):
+    """BASELINE C4 (4x1024 hidden, n_z=64, B=4096, bf16): too big for the oracle in seconds at full
+    batch, so: bitwise run-to-run determinism, finite decreasing cost, and oracle parity of the cost on
+    the same weights for the first 128 rows via evaluate on a B=128 replica."""
+    hs = [1024] * 4
+    archs = [make_arch("image", 784, 0, 0, 64, n_hidden=hs), make_arch("joint", 147, 0, 0, 64, n_hidden=hs)]
+    B = 4096
+    rng = np.random.default_rng(21)
+    X = synth_batch(rng, B, [784, 147], [True, False])
+    eps = rng.standard_normal((B, 64)).astype(np.float32)
+    kw = dict(binary=[True, False], transfer_fct="relu", weights=[50, 1], assoc_lambda=8.0, compute_dtype="bf16", seed=5)
+    runs = []
+    for _ in range(2):
+        m = V.AssocVariationalAutoEncoder(archs, batch_size=B, **kw)
+        assert m.n_params == 14900387
+        costs = [m.partial_fit(X, eps) for _ in range(5)]
+        runs.append((costs, m.get_params()))
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
+    costs = runs[0][0]
+    assert np.all(np.isfinite(costs)) and costs[-1] < costs[0]
+    small = V.AssocVariationalAutoEncoder(archs, batch_size=128, **kw)
+    ref = O.OracleAssocVAE(archs, [True, False], "relu", [50, 1], 8.0, 1e-3, 128, params_flat=small.get_params().astype(np.float64))
+    Xs, es = [x[:128] for x in X], eps[:128]
+    c, cr = small.evaluate_cost(Xs, es), ref.evaluate_cost(Xs, es)
+    assert abs(c - cr) <= 1e-3 * abs(cr), (c, cr)

@@ -1,0 +1,124 @@
+// Device-visible descriptors shared by the host planner (avae_host.hip) and the gfx950 kernels
+// (avae_kernels.hip).  A training step is a fixed list of launches; each launch runs ONE
+// grouped kernel over a table of work items that lives in HBM and never changes after
+// avae_create, which is what lets the whole step be captured once as a hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace avae {
+
+constexpr int kMaxMod = 4;
+constexpr int kThreads = 256;          // 4 wavefronts of 64
+constexpr int kTileBytesK = 128;       // bytes of K per staged tile row: 64 bf16 or 32 f32
+constexpr int kRowAlign = 128;         // row counts of GEMM operands are padded to this (largest tile)
+constexpr int kLatentRows = 64;        // rows per latent work-item tile
+constexpr int kCostHist = 4096;        // ring of per-step costs kept on the device
+
+// Work-item kinds.  All GEMM kinds compute C[M,N] = sum_k A[m][k] * B[n][k] with both operands
+// K-contiguous ("NT" form) and differ only in the LDS-staged epilogue.
+enum Kind : int {
+    K_FWD_HIDDEN = 0,    // Y = act(X_aug . W_aug)                      -> Y, Y^T          (vae_assoc.py:187,203,259,282)
+    K_FWD_HEAD = 1,      // [mu|lv] = H_aug . Whead_aug; z = mu+exp(lv/2)*eps -> mulv, Z, Z^T (:217-221,:102-103)
+    K_FWD_OUT_LOSS = 2,  // logits; recon loss + dLoss/dlogits         -> dA, dA^T, cost partial (:293-303,:321-328)
+    K_FWD_OUT_STORE = 3, // x_hat = sigmoid(logits) | logits           -> fp32 (inference)
+    K_DGRAD_HIDDEN = 4,  // dA_prev = (dA . W^T) * act'(Y_prev)        -> dA_prev, dA_prev^T
+    K_DGRAD_LATENT = 5,  // dz = dA . V1^T; dmu, dlv via reparam + static latent grads -> dH, dH^T
+    K_WGRAD = 6,         // dW_aug = X_aug^T . dA (bias grad = last row) -> fp32 gradient
+    K_LATENT = 7,        // KL(q||N(0,I)) + association penalty: cost partials + static (mu,lv) grads (:335-366)
+    K_COST = 8,          // fixed-order sum of the cost partials -> grad[cost slot]; bumps the step counter
+};
+
+struct WorkItem {
+    int kind;
+    int M, N, K;             // K is the padded extent (multiple of the K unit)
+    int lda, ldb;            // in elements of the compute type
+    int tiles_m, tiles_n;
+    int tile_base;           // first block of this item inside its launch
+    int act;                 // AVAE_ACT_*
+    int ld0, ld1, ld2, ldx;
+    int nz;
+    int binary;
+    int slot_base;           // first cost-partial slot written by this item
+    int n_slots;             // K_COST: number of partial slots to sum
+    int n_mod;               // K_LATENT
+    int bump_step;           // K_COST: 1 in training graphs
+    float scale;             // w/B_global (mean terms) or w (sum terms)
+    float lambda;            // K_LATENT
+    float inv_bg;            // 1/B_global
+    const void* A;
+    const void* B;
+    void* out0;
+    void* out1;
+    void* out2;
+    const void* aux0;
+    const void* aux1;
+    const void* aux2;
+    float* partial;          // cost partial slots
+    const float* mulv[kMaxMod];   // K_LATENT inputs  [B][2nz]
+    float* g0[kMaxMod];           // K_LATENT outputs [B][2nz]
+    float wts[kMaxMod];
+};
+
+struct DevState {
+    long long step;          // number of applied Adam steps
+    float last_cost;
+    float pad0;
+    float cost_hist[kCostHist];
+};
+
+// One dense layer's optimiser tile table entry (Adam + compute-dtype shadow refresh).
+struct AdamItem {
+    float* theta;
+    float* m;
+    float* v;
+    const float* g;
+    void* W;                 // shadow [in+1 (padded)][ld]   : B operand of dgrad
+    void* Wt;                // shadow [out (padded)][ldt]   : B operand of forward
+    int rows, cols;          // in+1, out
+    int ld, ldt;
+    int tiles_r, tiles_c, tile_base;
+    int pad;
+};
+
+struct AdamArgs {
+    const AdamItem* items;
+    int n_items;
+    int mode;                // 0: Adam update; 1: refresh shadows from theta only
+    float lr, beta1, beta2, eps;
+    DevState* st;
+    const float* cost_src;   // grad[cost slot]
+};
+
+// Input staging ("prep"): fp32 rows -> compute-dtype row-major + transposed copies (+ fp32 copy),
+// and the eps tensor (copied from the caller or generated with Philox4x32-10).
+struct PrepSeg {
+    const float* src; int src_ld;
+    int rows, cols;
+    float* dst32; int ld32;        // nullable
+    void* dstc; int ldc;           // row-major compute dtype
+    void* dstct; int ldct;         // transposed compute dtype, nullable
+    int tiles_r, tiles_c, tile_base;
+};
+struct PrepArgs {
+    PrepSeg seg[kMaxMod];
+    int n_seg;
+    int total_tiles;               // tiles of all segments; eps blocks follow
+    // eps
+    const float* eps_src;          // nullable -> Philox
+    float* eps_dst;                // nullable -> no eps work
+    int eps_rows, nz, eps_blocks;
+    int row_offset;
+    unsigned long long seed;
+    const DevState* st;
+    unsigned long long stream_salt;   // distinguishes train / eval / reconstruct draws
+};
+
+// launchers implemented in avae_kernels.hip
+void launch_grouped(int compute_dtype, int tile_cfg, const WorkItem* items, int n_items, int n_blocks,
+                    DevState* st, hipStream_t s);
+void launch_adam(int compute_dtype, const AdamArgs& a, int n_blocks, hipStream_t s);
+void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s);
+void launch_fill(void* base, int elem_bytes, unsigned bits, long long start, long long stride, int count, hipStream_t s);
+
+}  // namespace avae

@@ -1,0 +1,1026 @@
+// Host side of libavae: memory plan, work-item tables, hipGraph capture and the C ABI
+// (include/avae.h).  No per-step allocation: everything is carved once from one workspace.
+#include "avae_device.h"
+#include "../../include/avae.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using namespace avae;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Err : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIP_OK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            throw Err(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" +    \
+                      std::to_string(__LINE__) + ")");                                           \
+    } while (0)
+
+inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ----------------------------------------------------------------------------- memory plan
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off = rup(off + bytes, 256); return o; }
+};
+
+struct Dense {             // one dense layer, weights + bias as W_aug [(in+1)][ld]
+    int in = 0, out = 0;
+    int ld = 0;            // master / W-shadow leading dim = rup(out, KU)
+    int ldt = 0;           // W^T-shadow leading dim = rup(in+1, KU)
+    size_t master = 0;     // offset in floats inside the theta/m/v/g regions
+    size_t W = 0, Wt = 0;  // byte offsets in the workspace
+    bool head = false;     // [mu|sigma] fused head: flat layout is Wmu,bmu,Wsig,bsig
+};
+
+struct Act {               // activation or gradient: row-major [Bp][ld] + transposed [rup(width+1,128)][ldT]
+    int width = 0;
+    int ld = 0, ldT = 0;
+    size_t rm = 0, tr = 0;
+    bool ones = false;
+};
+
+struct Mod {
+    int n_in = 0, L = 0;
+    std::vector<int> hs;
+    std::vector<Dense> enc, dec;   // hidden layers
+    Dense head, outl;
+    Act X0, Z, dH, dO;
+    std::vector<Act> E, D, dE, dD;
+    size_t X32 = 0, mulv = 0, g0 = 0, out32 = 0;
+    int ld32 = 0;
+};
+
+struct Launch {
+    std::string name;
+    int cfg = 0, first = 0, count = 0, blocks = 0;
+};
+
+struct TimingRec { hipEvent_t a, b; int launch_name; };
+
+}  // namespace
+
+struct avae_handle {
+    avae_config cfg{};
+    std::mutex mu;
+    std::string err;
+    int es = 2, KU = 64;
+    int B = 0, Bp = 0, ldB = 0;   // batch, batch padded to 128 rows, rup(batch, KU)
+    int nz = 0, M = 0;
+    std::vector<Mod> mods;
+    size_t P_flat = 0, P_int = 0;            // flat API count, internal padded count (floats)
+    size_t off_theta = 0, off_m = 0, off_v = 0, off_g = 0;   // byte offsets; g has P_int + 64 floats
+    size_t off_eps = 0, off_partial = 0, off_state = 0, off_items = 0, off_adam = 0, off_inf = 0;
+    int n_partial = 0;
+    size_t ws_bytes = 0;
+    unsigned char* ws = nullptr;
+    bool own_ws = false;
+    hipStream_t cap_stream = nullptr;
+
+    std::vector<WorkItem> items;            // training + eval tables (host mirror)
+    std::vector<Launch> fwd, bwd;           // training launches
+    Launch cost_only;                       // eval: K_COST alone, no step bump
+    std::vector<AdamItem> adam_items;
+    int adam_blocks = 0;
+    // inference tables: per modality, device slots at off_inf
+    struct Inf { std::vector<WorkItem> items; std::vector<Launch> launches; int rows = -1; size_t dev_off = 0; };
+    std::vector<Inf> inf_enc, inf_dec;
+
+    hipGraphExec_t g_full = nullptr, g_bwd = nullptr, g_adam = nullptr, g_eval = nullptr;
+
+    bool timing = false;
+    std::vector<std::string> tnames;
+    std::vector<TimingRec> trecs;
+
+    template <typename T> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+    DevState* state() const { return at<DevState>(off_state); }
+    float* grad() const { return at<float>(off_g); }
+};
+
+namespace {
+
+Act make_act(Bump& b, int width, bool ones, int Bp, int ldB, int KU, int es) {
+    Act a;
+    a.width = width;
+    a.ones = ones;
+    a.ld = (int)rup(width + 1, KU);
+    a.ldT = ldB;
+    a.rm = b.take((size_t)Bp * a.ld * es);
+    a.tr = b.take(rup(width + 1, kRowAlign) * (size_t)a.ldT * es);
+    return a;
+}
+
+Dense make_dense(Bump& b, size_t& pint, int in, int out, int KU, int es, bool head) {
+    Dense d;
+    d.in = in; d.out = out; d.head = head;
+    d.ld = (int)rup(out, KU);
+    d.ldt = (int)rup(in + 1, KU);
+    d.master = pint;
+    pint += (size_t)(in + 1) * d.ld;
+    d.W = b.take(rup(in + 1, kRowAlign) * (size_t)d.ld * es);
+    d.Wt = b.take(rup(out, kRowAlign) * (size_t)d.ldt * es);
+    return d;
+}
+
+void check_config(const avae_config& c) {
+    if (c.abi_version != AVAE_ABI_VERSION) throw Err("avae_config.abi_version mismatch");
+    if (c.n_modalities < 1 || c.n_modalities > AVAE_MAX_MODALITIES) throw Err("n_modalities out of range");
+    if (c.n_z < 1 || c.n_z > 64) throw Err("n_z must be in [1,64] (the fused head/latent epilogue holds 2*n_z columns in one tile)");
+    if (c.batch_size < 1) throw Err("batch_size must be positive");
+    if (c.compute_dtype != AVAE_F32 && c.compute_dtype != AVAE_BF16) throw Err("compute_dtype must be AVAE_F32 or AVAE_BF16");
+    if (c.activation < AVAE_ACT_IDENTITY || c.activation > AVAE_ACT_TANH) throw Err("unknown activation");
+    for (int m = 0; m < c.n_modalities; ++m) {
+        const avae_modality& mo = c.mod[m];
+        if (mo.hidden_conv) throw Err("hidden_conv=1 (conv/deconv branch) is not built yet; only the MLP branch");
+        if (mo.n_input < 1) throw Err("n_input must be positive");
+        if (mo.n_hidden_layers < 1 || mo.n_hidden_layers > AVAE_MAX_HIDDEN) throw Err("n_hidden_layers out of range");
+        for (int k = 0; k < mo.n_hidden_layers; ++k)
+            if (mo.n_hidden[k] < 1) throw Err("hidden width must be positive");
+    }
+}
+
+// Lays out the whole workspace; with h->ws == nullptr it only computes sizes.
+void plan_memory(avae_handle* h) {
+    const avae_config& c = h->cfg;
+    h->es = c.compute_dtype == AVAE_BF16 ? 2 : 4;
+    h->KU = kTileBytesK / h->es;
+    h->B = c.batch_size;
+    h->Bp = (int)rup(h->B, kRowAlign);
+    h->ldB = (int)rup(h->B, h->KU);
+    h->nz = c.n_z;
+    h->M = c.n_modalities;
+    const int KU = h->KU, es = h->es, Bp = h->Bp, ldB = h->ldB, nz = h->nz, B = h->B;
+    Bump b;
+    size_t pint = 0, pflat = 0;
+    h->mods.clear();
+    for (int m = 0; m < h->M; ++m) {
+        const avae_modality& mo = c.mod[m];
+        Mod md;
+        md.n_in = mo.n_input;
+        md.L = mo.n_hidden_layers;
+        md.hs.assign(mo.n_hidden, mo.n_hidden + md.L);
+        int prev = md.n_in;
+        for (int k = 0; k < md.L; ++k) { md.enc.push_back(make_dense(b, pint, prev, md.hs[k], KU, es, false)); pflat += (size_t)(prev + 1) * md.hs[k]; prev = md.hs[k]; }
+        md.head = make_dense(b, pint, prev, 2 * nz, KU, es, true);
+        pflat += (size_t)(prev + 1) * 2 * nz;
+        prev = nz;
+        for (int k = 0; k < md.L; ++k) { md.dec.push_back(make_dense(b, pint, prev, md.hs[k], KU, es, false)); pflat += (size_t)(prev + 1) * md.hs[k]; prev = md.hs[k]; }
+        md.outl = make_dense(b, pint, prev, md.n_in, KU, es, false);
+        pflat += (size_t)(prev + 1) * md.n_in;
+
+        md.X0 = make_act(b, md.n_in, true, Bp, ldB, KU, es);
+        for (int k = 0; k < md.L; ++k) md.E.push_back(make_act(b, md.hs[k], true, Bp, ldB, KU, es));
+        md.Z = make_act(b, nz, true, Bp, ldB, KU, es);
+        for (int k = 0; k < md.L; ++k) md.D.push_back(make_act(b, md.hs[k], true, Bp, ldB, KU, es));
+        for (int k = 0; k < md.L; ++k) md.dE.push_back(make_act(b, md.hs[k], false, Bp, ldB, KU, es));
+        md.dH = make_act(b, 2 * nz, false, Bp, ldB, KU, es);
+        for (int k = 0; k < md.L; ++k) md.dD.push_back(make_act(b, md.hs[k], false, Bp, ldB, KU, es));
+        md.dO = make_act(b, md.n_in, false, Bp, ldB, KU, es);
+        md.ld32 = (int)rup(md.n_in, 4);
+        md.X32 = b.take((size_t)B * md.ld32 * 4);
+        md.out32 = b.take((size_t)B * md.ld32 * 4);
+        md.mulv = b.take((size_t)B * 2 * nz * 4);
+        md.g0 = b.take((size_t)B * 2 * nz * 4);
+        h->mods.push_back(std::move(md));
+    }
+    h->P_int = pint;
+    h->P_flat = pflat;
+    h->off_theta = b.take(pint * 4);
+    h->off_m = b.take(pint * 4);
+    h->off_v = b.take(pint * 4);
+    h->off_g = b.take((pint + 64) * 4);      // + cost slot (element P_int), padded
+    h->off_eps = b.take((size_t)B * nz * 4);
+    // cost partial slots: one per output-loss tile (64-wide tiles bound the count) + latent tiles
+    int slots = (B + kLatentRows - 1) / kLatentRows;
+    for (int m = 0; m < h->M; ++m) slots += ((B + 63) / 64) * ((h->mods[m].n_in + 63) / 64);
+    h->n_partial = slots;
+    h->off_partial = b.take((size_t)slots * 4);
+    h->off_state = b.take(sizeof(DevState));
+    // work-item tables: training items + eval cost item; inference tables per modality
+    size_t n_train_items = 0;
+    for (int m = 0; m < h->M; ++m) n_train_items += 6 * (size_t)h->mods[m].L + 8;
+    n_train_items += 8;
+    h->off_items = b.take(n_train_items * sizeof(WorkItem));
+    size_t n_adam = 0;
+    for (int m = 0; m < h->M; ++m) n_adam += 2 * (size_t)h->mods[m].L + 2;
+    h->off_adam = b.take(n_adam * sizeof(AdamItem));
+    h->off_inf = b.off;
+    for (int m = 0; m < h->M; ++m) b.take(2 * ((size_t)h->mods[m].L + 1) * sizeof(WorkItem));
+    h->ws_bytes = b.off;
+}
+
+// ----------------------------------------------------------------------------- flat <-> internal
+template <bool ToInternal>
+void convert_params(const avae_handle* h, float* flat, float* internal) {
+    size_t f = 0;
+    auto dense = [&](const Dense& d) {
+        float* I = internal + d.master;
+        if (!d.head) {
+            for (int r = 0; r < d.in; ++r)
+                for (int c = 0; c < d.out; ++c, ++f) { if (ToInternal) I[(size_t)r * d.ld + c] = flat[f]; else flat[f] = I[(size_t)r * d.ld + c]; }
+            for (int c = 0; c < d.out; ++c, ++f) { if (ToInternal) I[(size_t)d.in * d.ld + c] = flat[f]; else flat[f] = I[(size_t)d.in * d.ld + c]; }
+        } else {
+            const int nz = d.out / 2;
+            for (int half = 0; half < 2; ++half) {
+                for (int r = 0; r < d.in; ++r)
+                    for (int c = 0; c < nz; ++c, ++f) { float& x = I[(size_t)r * d.ld + half * nz + c]; if (ToInternal) x = flat[f]; else flat[f] = x; }
+                for (int c = 0; c < nz; ++c, ++f) { float& x = I[(size_t)d.in * d.ld + half * nz + c]; if (ToInternal) x = flat[f]; else flat[f] = x; }
+            }
+        }
+    };
+    for (const Mod& md : h->mods) {
+        for (const Dense& d : md.enc) dense(d);
+        dense(md.head);
+        for (const Dense& d : md.dec) dense(d);
+        dense(md.outl);
+    }
+    if (f != h->P_flat) throw Err("internal error: flat parameter count mismatch");
+}
+
+// ----------------------------------------------------------------------------- work items
+WorkItem gemm_item(int kind, int M, int N, int K, const void* A, int lda, const void* B, int ldb) {
+    WorkItem w;
+    std::memset(&w, 0, sizeof(w));
+    w.kind = kind; w.M = M; w.N = N; w.K = K; w.A = A; w.lda = lda; w.B = B; w.ldb = ldb;
+    return w;
+}
+
+struct Builder {
+    avae_handle* h;
+    std::vector<WorkItem>& items;
+    int B;      // rows of this plan (batch or inference rows)
+    bool train; // write transposed copies
+    int next_slot = 0;
+    Builder(avae_handle* h_, std::vector<WorkItem>& it, int rows, bool tr) : h(h_), items(it), B(rows), train(tr) {}
+    template <typename T> T* p(size_t off) const { return h->at<T>(off); }
+    int K_of(int n) const { return (int)rup(n, h->KU); }
+
+    WorkItem fwd_hidden(const Act& in, const Dense& d, const Act& out) {
+        WorkItem w = gemm_item(K_FWD_HIDDEN, B, d.out, K_of(d.in + 1), p<void>(in.rm), in.ld, p<void>(d.Wt), d.ldt);
+        w.act = h->cfg.activation;
+        w.out0 = p<void>(out.rm); w.ld0 = out.ld;
+        w.out1 = train ? p<void>(out.tr) : nullptr; w.ld1 = out.ldT;
+        return w;
+    }
+    WorkItem fwd_head(const Mod& md, bool with_z) {
+        const Act& in = md.E.back();
+        WorkItem w = gemm_item(K_FWD_HEAD, B, 2 * h->nz, K_of(md.head.in + 1), p<void>(in.rm), in.ld, p<void>(md.head.Wt), md.head.ldt);
+        w.nz = h->nz;
+        w.out0 = p<void>(md.mulv); w.ld0 = 2 * h->nz;
+        w.out1 = with_z ? p<void>(md.Z.rm) : nullptr; w.ld1 = md.Z.ld;
+        w.out2 = (with_z && train) ? p<void>(md.Z.tr) : nullptr; w.ld2 = md.Z.ldT;
+        w.aux0 = p<void>(h->off_eps);
+        return w;
+    }
+    WorkItem fwd_out(const Mod& md, int m, bool loss) {
+        const Act& in = md.D.back();
+        WorkItem w = gemm_item(loss ? K_FWD_OUT_LOSS : K_FWD_OUT_STORE, B, md.n_in, K_of(md.outl.in + 1), p<void>(in.rm), in.ld,
+                               p<void>(md.outl.Wt), md.outl.ldt);
+        w.binary = h->cfg.mod[m].binary ? 1 : 0;
+        const float bg = (float)(h->cfg.batch_global > 0 ? h->cfg.batch_global : h->cfg.batch_size);
+        if (loss) {
+            w.scale = w.binary ? h->cfg.mod[m].weight / bg : h->cfg.mod[m].weight;
+            w.aux0 = p<void>(md.X32); w.ldx = md.ld32;
+            w.out0 = p<void>(md.dO.rm); w.ld0 = md.dO.ld;
+            w.out1 = p<void>(md.dO.tr); w.ld1 = md.dO.ldT;
+            w.partial = p<float>(h->off_partial);
+        } else {
+            w.out0 = p<void>(md.out32); w.ld0 = md.ld32;
+        }
+        return w;
+    }
+    WorkItem dgrad_hidden(const Act& dA, const Dense& d, const Act& yprev, const Act& dprev) {
+        WorkItem w = gemm_item(K_DGRAD_HIDDEN, B, d.in, K_of(d.out), p<void>(dA.rm), dA.ld, p<void>(d.W), d.ld);
+        w.act = h->cfg.activation;
+        w.aux0 = p<void>(yprev.rm); w.ldx = yprev.ld;
+        w.out0 = p<void>(dprev.rm); w.ld0 = dprev.ld;
+        w.out1 = p<void>(dprev.tr); w.ld1 = dprev.ldT;
+        return w;
+    }
+    WorkItem dgrad_latent(const Mod& md) {
+        const Dense& d = md.dec[0];
+        const Act& dA = md.dD[0];
+        WorkItem w = gemm_item(K_DGRAD_LATENT, B, h->nz, K_of(d.out), p<void>(dA.rm), dA.ld, p<void>(d.W), d.ld);
+        w.nz = h->nz;
+        w.aux0 = p<void>(md.mulv); w.aux1 = p<void>(h->off_eps); w.aux2 = p<void>(md.g0);
+        w.out0 = p<void>(md.dH.rm); w.ld0 = md.dH.ld;
+        w.out1 = p<void>(md.dH.tr); w.ld1 = md.dH.ldT;
+        return w;
+    }
+    WorkItem wgrad(const Act& x, const Dense& d, const Act& dA) {
+        WorkItem w = gemm_item(K_WGRAD, d.in + 1, d.out, K_of(B), p<void>(x.tr), x.ldT, p<void>(dA.tr), dA.ldT);
+        w.out0 = h->grad() + d.master; w.ld0 = d.ld;
+        return w;
+    }
+    WorkItem latent() {
+        WorkItem w;
+        std::memset(&w, 0, sizeof(w));
+        w.kind = K_LATENT; w.M = B; w.nz = h->nz; w.n_mod = h->M;
+        const float bg = (float)(h->cfg.batch_global > 0 ? h->cfg.batch_global : h->cfg.batch_size);
+        w.inv_bg = 1.0f / bg; w.lambda = h->cfg.assoc_lambda;
+        for (int m = 0; m < h->M; ++m) { w.mulv[m] = p<float>(h->mods[m].mulv); w.g0[m] = p<float>(h->mods[m].g0); w.wts[m] = h->cfg.mod[m].weight; }
+        w.partial = p<float>(h->off_partial);
+        return w;
+    }
+    WorkItem cost(bool bump) {
+        WorkItem w;
+        std::memset(&w, 0, sizeof(w));
+        w.kind = K_COST; w.partial = p<float>(h->off_partial); w.bump_step = bump ? 1 : 0;
+        w.out0 = h->grad() + h->P_int;
+        return w;
+    }
+};
+
+// Fixes the tile configuration of one launch and lays its items' tiles out back to back.
+Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, int count, const std::string& name, int* next_slot) {
+    Launch L;
+    L.name = name; L.first = first; L.count = count;
+    bool need128 = false;
+    long tiles128 = 0;
+    for (int i = first; i < first + count; ++i) {
+        const WorkItem& w = items[i];
+        if ((w.kind == K_FWD_HEAD || w.kind == K_DGRAD_LATENT) && 2 * w.nz > 64) need128 = true;
+        if (w.kind <= K_WGRAD) tiles128 += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
+    }
+    L.cfg = (need128 || tiles128 >= 192) ? 1 : 0;
+    const int T = L.cfg ? 128 : 64;
+    int base = 0;
+    for (int i = first; i < first + count; ++i) {
+        WorkItem& w = items[i];
+        w.tile_base = base;
+        if (w.kind <= K_WGRAD) {
+            w.tiles_m = (w.M + T - 1) / T;
+            w.tiles_n = (w.N + T - 1) / T;
+            if ((w.kind == K_FWD_HEAD || w.kind == K_DGRAD_LATENT) && w.tiles_n != 1) throw Err("internal error: head tile");
+            if (w.kind == K_FWD_OUT_LOSS) { w.slot_base = *next_slot; *next_slot += w.tiles_m * w.tiles_n; }
+            base += w.tiles_m * w.tiles_n;
+        } else if (w.kind == K_LATENT) {
+            w.tiles_m = (w.M + kLatentRows - 1) / kLatentRows; w.tiles_n = 1;
+            w.slot_base = *next_slot; *next_slot += w.tiles_m;
+            base += w.tiles_m;
+        } else {   // K_COST
+            w.tiles_m = w.tiles_n = 1;
+            w.n_slots = *next_slot;
+            base += 1;
+        }
+    }
+    L.blocks = base;
+    if (*next_slot > h->n_partial) throw Err("internal error: cost partial slots overflow");
+    return L;
+}
+
+void build_training_plan(avae_handle* h) {
+    h->items.clear(); h->fwd.clear(); h->bwd.clear();
+    Builder bd(h, h->items, h->B, true);
+    int slot = 0;
+    int Lmax = 0;
+    for (const Mod& md : h->mods) Lmax = std::max(Lmax, md.L);
+    auto group = [&](const std::string& name, std::vector<Launch>& dst, auto&& fill) {
+        const int first = (int)h->items.size();
+        fill();
+        const int count = (int)h->items.size() - first;
+        if (count > 0) dst.push_back(finish_launch(h, h->items, first, count, name, &slot));
+    };
+    // ---- forward.  Modalities with fewer hidden layers simply sit out a launch; data dependencies
+    // are per modality and launches are stream-ordered, so this is always safe.
+    for (int k = 0; k < Lmax; ++k)
+        group("fwd_enc" + std::to_string(k + 1), h->fwd, [&] {
+            for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.X0 : md.E[k - 1], md.enc[k], md.E[k]));
+        });
+    group("fwd_head", h->fwd, [&] { for (Mod& md : h->mods) h->items.push_back(bd.fwd_head(md, true)); });
+    for (int k = 0; k < Lmax; ++k)
+        group("fwd_dec" + std::to_string(k + 1), h->fwd, [&] {
+            for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k]));
+            if (k == 0) h->items.push_back(bd.latent());     // needs every modality's (mu, lv): ready after fwd_head
+        });
+    group("fwd_out_loss", h->fwd, [&] { for (int m = 0; m < h->M; ++m) h->items.push_back(bd.fwd_out(h->mods[m], m, true)); });
+    // ---- backward: each launch = the dgrad through layer l and the wgrad of layer l (both need only dA_l)
+    group("bwd_out", h->bwd, [&] {
+        for (Mod& md : h->mods) {
+            h->items.push_back(bd.dgrad_hidden(md.dO, md.outl, md.D.back(), md.dD.back()));
+            h->items.push_back(bd.wgrad(md.D.back(), md.outl, md.dO));
+        }
+    });
+    for (int k = Lmax - 1; k >= 1; --k)
+        group("bwd_dec" + std::to_string(k + 1), h->bwd, [&] {
+            for (Mod& md : h->mods) if (k < md.L) {
+                h->items.push_back(bd.dgrad_hidden(md.dD[k], md.dec[k], md.D[k - 1], md.dD[k - 1]));
+                h->items.push_back(bd.wgrad(md.D[k - 1], md.dec[k], md.dD[k]));
+            }
+        });
+    group("bwd_dec1_latent", h->bwd, [&] {
+        for (Mod& md : h->mods) {
+            h->items.push_back(bd.dgrad_latent(md));
+            h->items.push_back(bd.wgrad(md.Z, md.dec[0], md.dD[0]));
+        }
+    });
+    group("bwd_head", h->bwd, [&] {
+        for (Mod& md : h->mods) {
+            h->items.push_back(bd.dgrad_hidden(md.dH, md.head, md.E.back(), md.dE.back()));
+            h->items.push_back(bd.wgrad(md.E.back(), md.head, md.dH));
+        }
+    });
+    for (int k = Lmax - 1; k >= 1; --k)
+        group("bwd_enc" + std::to_string(k + 1), h->bwd, [&] {
+            for (Mod& md : h->mods) if (k < md.L) {
+                h->items.push_back(bd.dgrad_hidden(md.dE[k], md.enc[k], md.E[k - 1], md.dE[k - 1]));
+                h->items.push_back(bd.wgrad(md.E[k - 1], md.enc[k], md.dE[k]));
+            }
+        });
+    group("bwd_enc1", h->bwd, [&] {
+        for (Mod& md : h->mods) h->items.push_back(bd.wgrad(md.X0, md.enc[0], md.dE[0]));
+        h->items.push_back(bd.cost(true));
+    });
+    // ---- eval: forward launches + a lone cost reduction that does not bump the step
+    {
+        const int first = (int)h->items.size();
+        h->items.push_back(bd.cost(false));
+        h->cost_only = finish_launch(h, h->items, first, 1, "cost_reduce", &slot);
+    }
+    if (h->items.size() * sizeof(WorkItem) > h->off_adam - h->off_items) throw Err("internal error: item table overflow");
+
+    // ---- Adam tiles
+    h->adam_items.clear();
+    int base = 0;
+    auto add = [&](const Dense& d) {
+        AdamItem a;
+        std::memset(&a, 0, sizeof(a));
+        a.theta = h->at<float>(h->off_theta) + d.master;
+        a.m = h->at<float>(h->off_m) + d.master;
+        a.v = h->at<float>(h->off_v) + d.master;
+        a.g = h->grad() + d.master;
+        a.W = h->at<void>(d.W); a.Wt = h->at<void>(d.Wt);
+        a.rows = d.in + 1; a.cols = d.out; a.ld = d.ld; a.ldt = d.ldt;
+        a.tiles_r = (a.rows + 63) / 64; a.tiles_c = (a.cols + 63) / 64; a.tile_base = base;
+        base += a.tiles_r * a.tiles_c;
+        h->adam_items.push_back(a);
+    };
+    for (const Mod& md : h->mods) {
+        for (const Dense& d : md.enc) add(d);
+        add(md.head);
+        for (const Dense& d : md.dec) add(d);
+        add(md.outl);
+    }
+    h->adam_blocks = base;
+}
+
+void build_inference(avae_handle* h, int m, bool enc, int rows) {
+    avae_handle::Inf& inf = enc ? h->inf_enc[m] : h->inf_dec[m];
+    if (inf.rows == rows) return;
+    inf.items.clear(); inf.launches.clear();
+    Builder bd(h, inf.items, rows, false);
+    Mod& md = h->mods[m];
+    int slot = 0;
+    auto one = [&](const WorkItem& w, const std::string& name) {
+        inf.items.push_back(w);
+        inf.launches.push_back(finish_launch(h, inf.items, (int)inf.items.size() - 1, 1, name, &slot));
+    };
+    if (enc) {
+        for (int k = 0; k < md.L; ++k) one(bd.fwd_hidden(k == 0 ? md.X0 : md.E[k - 1], md.enc[k], md.E[k]), "inf_enc");
+        one(bd.fwd_head(md, true), "inf_head");
+    } else {
+        for (int k = 0; k < md.L; ++k) one(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k]), "inf_dec");
+        one(bd.fwd_out(md, m, false), "inf_out");
+    }
+    inf.rows = rows;
+}
+
+// ----------------------------------------------------------------------------- execution
+int tname_id(avae_handle* h, const std::string& n) {
+    for (size_t i = 0; i < h->tnames.size(); ++i) if (h->tnames[i] == n) return (int)i;
+    h->tnames.push_back(n);
+    return (int)h->tnames.size() - 1;
+}
+
+struct Timed {
+    avae_handle* h; hipStream_t s; bool on; hipEvent_t a = nullptr, b = nullptr; int id = 0;
+    Timed(avae_handle* h_, hipStream_t s_, const std::string& name) : h(h_), s(s_), on(h_->timing && h_->trecs.size() < 200000) {
+        if (!on) return;
+        id = tname_id(h, name);
+        HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
+        HIP_OK(hipEventRecord(a, s));
+    }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(b, s);
+        h->trecs.push_back(TimingRec{a, b, id});
+    }
+};
+
+void run_launches(avae_handle* h, const std::vector<Launch>& ls, const WorkItem* dev_items, hipStream_t s) {
+    for (const Launch& L : ls) {
+        Timed t(h, s, L.name);
+        launch_grouped(h->cfg.compute_dtype, L.cfg, dev_items + L.first, L.count, L.blocks, h->state(), s);
+    }
+}
+
+void run_adam(avae_handle* h, int mode, hipStream_t s) {
+    AdamArgs a;
+    a.items = h->at<AdamItem>(h->off_adam);
+    a.n_items = (int)h->adam_items.size();
+    a.mode = mode;
+    a.lr = h->cfg.learning_rate; a.beta1 = h->cfg.beta1; a.beta2 = h->cfg.beta2; a.eps = h->cfg.adam_eps;
+    a.st = h->state();
+    a.cost_src = h->grad() + h->P_int;
+    Timed t(h, s, mode == 0 ? "adam" : "shadow_refresh");
+    launch_adam(h->cfg.compute_dtype, a, h->adam_blocks, s);
+}
+
+// stages the caller's batch (and eps) into the internal compute-dtype buffers
+void run_prep_batch(avae_handle* h, const float* const* x, const int32_t* x_ld, const float* eps, int rows,
+                    unsigned long long salt, hipStream_t s) {
+    PrepArgs a;
+    std::memset(&a, 0, sizeof(a));
+    int base = 0;
+    for (int m = 0; m < h->M; ++m) {
+        const Mod& md = h->mods[m];
+        PrepSeg& g = a.seg[m];
+        g.src = x[m]; g.src_ld = (x_ld && x_ld[m] > 0) ? x_ld[m] : md.n_in;
+        g.rows = rows; g.cols = md.n_in;
+        g.dst32 = h->at<float>(md.X32); g.ld32 = md.ld32;
+        g.dstc = h->at<void>(md.X0.rm); g.ldc = md.X0.ld;
+        g.dstct = h->at<void>(md.X0.tr); g.ldct = md.X0.ldT;
+        g.tiles_r = (rows + 63) / 64; g.tiles_c = (md.n_in + 63) / 64; g.tile_base = base;
+        base += g.tiles_r * g.tiles_c;
+    }
+    a.n_seg = h->M; a.total_tiles = base;
+    a.eps_src = eps; a.eps_dst = h->at<float>(h->off_eps); a.eps_rows = rows; a.nz = h->nz;
+    a.eps_blocks = (rows * ((h->nz + 3) / 4) + kThreads - 1) / kThreads;
+    a.row_offset = h->cfg.row_offset; a.seed = h->cfg.seed; a.st = h->state(); a.stream_salt = salt;
+    Timed t(h, s, "prep");
+    launch_prep(h->cfg.compute_dtype, a, s);
+}
+
+void run_prep_single(avae_handle* h, const float* src, int src_ld, int rows, int cols, const Act& dst, float* dst32, int ld32,
+                     bool do_eps, const float* eps, unsigned long long salt, hipStream_t s) {
+    PrepArgs a;
+    std::memset(&a, 0, sizeof(a));
+    if (src) {
+        PrepSeg& g = a.seg[0];
+        g.src = src; g.src_ld = src_ld; g.rows = rows; g.cols = cols;
+        g.dst32 = dst32; g.ld32 = ld32;
+        g.dstc = h->at<void>(dst.rm); g.ldc = dst.ld;
+        g.dstct = nullptr;               // inference never touches the transposed (K = batch) copies
+        g.tiles_r = (rows + 63) / 64; g.tiles_c = (cols + 63) / 64; g.tile_base = 0;
+        a.n_seg = 1; a.total_tiles = g.tiles_r * g.tiles_c;
+    }
+    if (do_eps) {
+        a.eps_src = eps; a.eps_dst = h->at<float>(h->off_eps); a.eps_rows = rows; a.nz = h->nz;
+        a.eps_blocks = (rows * ((h->nz + 3) / 4) + kThreads - 1) / kThreads;
+    }
+    a.row_offset = h->cfg.row_offset; a.seed = h->cfg.seed; a.st = h->state(); a.stream_salt = salt;
+    launch_prep(h->cfg.compute_dtype, a, s);
+}
+
+hipGraphExec_t capture(avae_handle* h, const std::function<void(hipStream_t)>& body) {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIP_OK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    try { body(h->cap_stream); } catch (...) { (void)hipStreamEndCapture(h->cap_stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
+    HIP_OK(hipStreamEndCapture(h->cap_stream, &g));
+    HIP_OK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HIP_OK(hipGraphDestroy(g));
+    return ge;
+}
+
+void fill_ones(avae_handle* h, const Act& a, hipStream_t s) {
+    if (!a.ones) return;
+    const unsigned bits = h->es == 2 ? 0x3F80u : 0x3F800000u;
+    launch_fill(h->at<void>(a.rm), h->es, bits, a.width, a.ld, h->B, s);             // column `width`, rows < B
+    launch_fill(h->at<void>(a.tr), h->es, bits, (long long)a.width * a.ldT, 1, h->B, s);   // row `width`, cols < B
+}
+
+void init_device(avae_handle* h) {
+    hipStream_t s = h->cap_stream;
+    HIP_OK(hipMemsetAsync(h->ws, 0, h->ws_bytes, s));
+    for (const Mod& md : h->mods) {
+        fill_ones(h, md.X0, s);
+        for (const Act& a : md.E) fill_ones(h, a, s);
+        fill_ones(h, md.Z, s);
+        for (const Act& a : md.D) fill_ones(h, a, s);
+    }
+    build_training_plan(h);
+    HIP_OK(hipMemcpyAsync(h->at<void>(h->off_items), h->items.data(), h->items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(h->at<void>(h->off_adam), h->adam_items.data(), h->adam_items.size() * sizeof(AdamItem), hipMemcpyHostToDevice, s));
+    size_t off = h->off_inf;
+    h->inf_enc.assign(h->M, avae_handle::Inf());
+    h->inf_dec.assign(h->M, avae_handle::Inf());
+    for (int m = 0; m < h->M; ++m) {
+        h->inf_enc[m].dev_off = off; off += ((size_t)h->mods[m].L + 1) * sizeof(WorkItem);
+        h->inf_dec[m].dev_off = off; off += ((size_t)h->mods[m].L + 1) * sizeof(WorkItem);
+    }
+    HIP_OK(hipStreamSynchronize(s));
+    if (h->cfg.use_graph) {
+        const WorkItem* di = h->at<WorkItem>(h->off_items);
+        const bool tsave = h->timing;
+        h->timing = false;
+        h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, di, cs); run_launches(h, h->bwd, di, cs); });
+        h->g_adam = capture(h, [&](hipStream_t cs) { run_adam(h, 0, cs); });
+        h->g_full = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, di, cs); run_launches(h, h->bwd, di, cs); run_adam(h, 0, cs); });
+        h->g_eval = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, di, cs); run_launches(h, std::vector<Launch>{h->cost_only}, di, cs); });
+        h->timing = tsave;
+    }
+}
+
+void do_backward(avae_handle* h, hipStream_t s) {
+    const WorkItem* di = h->at<WorkItem>(h->off_items);
+    if (h->g_bwd && !h->timing) HIP_OK(hipGraphLaunch(h->g_bwd, s));
+    else { run_launches(h, h->fwd, di, s); run_launches(h, h->bwd, di, s); }
+}
+
+void do_apply(avae_handle* h, hipStream_t s) {
+    if (h->g_adam && !h->timing) HIP_OK(hipGraphLaunch(h->g_adam, s));
+    else run_adam(h, 0, s);
+}
+
+void fetch_cost(avae_handle* h, float* cost_host, bool from_state, hipStream_t s) {
+    if (!cost_host) return;
+    const void* src = from_state ? (const void*)&h->state()->last_cost : (const void*)(h->grad() + h->P_int);
+    HIP_OK(hipMemcpyAsync(cost_host, src, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+}
+
+void copy_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, hipStream_t s) {
+    HIP_OK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, s));
+}
+
+template <typename F> int guarded(avae_handle* h, F&& f) {
+    if (!h) return 1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    try {
+        HIP_OK(hipSetDevice(h->cfg.device));
+        f();
+        return 0;
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return 2;
+    }
+}
+
+void master_to_host(avae_handle* h, size_t off, std::vector<float>& host) {
+    host.resize(h->P_int);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(host.data(), h->at<void>(off), h->P_int * 4, hipMemcpyDeviceToHost));
+}
+void host_to_master(avae_handle* h, size_t off, const std::vector<float>& host) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(h->at<void>(off), host.data(), h->P_int * 4, hipMemcpyHostToDevice));
+}
+
+}  // namespace
+
+// ============================================================================= C ABI
+extern "C" {
+
+int avae_workspace_bytes(const avae_config* cfg, size_t* bytes) {
+    try {
+        if (!cfg || !bytes) throw Err("null argument");
+        check_config(*cfg);
+        avae_handle tmp;
+        tmp.cfg = *cfg;
+        plan_memory(&tmp);
+        *bytes = tmp.ws_bytes;
+        return 0;
+    } catch (const std::exception& e) { g_create_error = e.what(); return 2; }
+}
+
+int avae_create(const avae_config* cfg, avae_handle** out) {
+    avae_handle* h = nullptr;
+    try {
+        if (!cfg || !out) throw Err("null argument");
+        check_config(*cfg);
+        h = new avae_handle();
+        h->cfg = *cfg;
+        if (h->cfg.beta1 == 0.f && h->cfg.beta2 == 0.f && h->cfg.adam_eps == 0.f) { h->cfg.beta1 = 0.9f; h->cfg.beta2 = 0.999f; h->cfg.adam_eps = 1e-8f; }
+        int ndev = 0;
+        HIP_OK(hipGetDeviceCount(&ndev));
+        if (ndev < 1) throw Err("no HIP device: libavae has no CPU fallback");
+        if (h->cfg.device < 0 || h->cfg.device >= ndev) throw Err("device ordinal out of range");
+        HIP_OK(hipSetDevice(h->cfg.device));
+        hipDeviceProp_t prop;
+        HIP_OK(hipGetDeviceProperties(&prop, h->cfg.device));
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+            throw Err(std::string("libavae is built for gfx950 only; device is ") + prop.gcnArchName);
+        plan_memory(h);
+        if (cfg->workspace) {
+            if (cfg->workspace_bytes < h->ws_bytes) throw Err("workspace too small");
+            if (reinterpret_cast<uintptr_t>(cfg->workspace) % 256) throw Err("workspace must be 256-byte aligned");
+            h->ws = reinterpret_cast<unsigned char*>(cfg->workspace);
+        } else {
+            HIP_OK(hipMalloc(reinterpret_cast<void**>(&h->ws), h->ws_bytes));
+            h->own_ws = true;
+        }
+        HIP_OK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+        init_device(h);
+        *out = h;
+        return 0;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        if (h) { if (h->own_ws && h->ws) (void)hipFree(h->ws); if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream); delete h; }
+        return 2;
+    }
+}
+
+void avae_destroy(avae_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (hipGraphExec_t g : {h->g_full, h->g_bwd, h->g_adam, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
+    for (TimingRec& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->own_ws && h->ws) (void)hipFree(h->ws);
+    delete h;
+}
+
+const char* avae_last_error(const avae_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int avae_param_count(const avae_handle* h, size_t* n) {
+    if (!h || !n) return 1;
+    *n = h->P_flat;
+    return 0;
+}
+
+int avae_get_params(avae_handle* h, float* host_dst) {
+    return guarded(h, [&] { std::vector<float> I; master_to_host(h, h->off_theta, I); convert_params<false>(h, host_dst, I.data()); });
+}
+
+int avae_set_params(avae_handle* h, const float* host_src) {
+    return guarded(h, [&] {
+        std::vector<float> I(h->P_int, 0.0f);
+        convert_params<true>(h, const_cast<float*>(host_src), I.data());
+        host_to_master(h, h->off_theta, I);
+        run_adam(h, 1, nullptr);          // rebuild the compute-dtype shadows W / W^T
+        HIP_OK(hipDeviceSynchronize());
+    });
+}
+
+int avae_get_grads(avae_handle* h, float* host_dst) {
+    return guarded(h, [&] { std::vector<float> I; master_to_host(h, h->off_g, I); convert_params<false>(h, host_dst, I.data()); });
+}
+
+int avae_get_opt_state(avae_handle* h, float* host_m, float* host_v, int64_t* step) {
+    return guarded(h, [&] {
+        std::vector<float> I;
+        if (host_m) { master_to_host(h, h->off_m, I); convert_params<false>(h, host_m, I.data()); }
+        if (host_v) { master_to_host(h, h->off_v, I); convert_params<false>(h, host_v, I.data()); }
+        if (step) { long long st = 0; HIP_OK(hipDeviceSynchronize()); HIP_OK(hipMemcpy(&st, &h->state()->step, sizeof(st), hipMemcpyDeviceToHost)); *step = st; }
+    });
+}
+
+int avae_set_opt_state(avae_handle* h, const float* host_m, const float* host_v, int64_t step) {
+    return guarded(h, [&] {
+        std::vector<float> I(h->P_int, 0.0f);
+        if (host_m) { convert_params<true>(h, const_cast<float*>(host_m), I.data()); host_to_master(h, h->off_m, I); }
+        if (host_v) { std::fill(I.begin(), I.end(), 0.0f); convert_params<true>(h, const_cast<float*>(host_v), I.data()); host_to_master(h, h->off_v, I); }
+        long long st = step;
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(&h->state()->step, &st, sizeof(st), hipMemcpyHostToDevice));
+    });
+}
+
+int avae_step_backward(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, void* stream) {
+    return guarded(h, [&] {
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull /*train*/, s);
+        do_backward(h, s);
+    });
+}
+
+int avae_step_apply(avae_handle* h, float* cost_host, void* stream) {
+    return guarded(h, [&] {
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        do_apply(h, s);
+        fetch_cost(h, cost_host, true, s);
+    });
+}
+
+int avae_train_step(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, float* cost_host, void* stream) {
+    return guarded(h, [&] {
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, s);
+        if (h->g_full && !h->timing) HIP_OK(hipGraphLaunch(h->g_full, s));
+        else { do_backward(h, s); do_apply(h, s); }
+        fetch_cost(h, cost_host, true, s);
+    });
+}
+
+int avae_grad_buffer(avae_handle* h, float** dev_ptr, size_t* n_floats) {
+    if (!h || !dev_ptr || !n_floats) return 1;
+    *dev_ptr = h->grad();
+    *n_floats = h->P_int + 1;     // gradient (internal padded layout) + the cost slot
+    return 0;
+}
+
+int avae_cost_history(avae_handle* h, int32_t n, float* host_dst, int64_t* last_step) {
+    return guarded(h, [&] {
+        if (n < 0 || n > kCostHist) throw Err("cost history request out of range");
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<unsigned char> buf(sizeof(DevState));
+        HIP_OK(hipMemcpy(buf.data(), h->state(), sizeof(DevState), hipMemcpyDeviceToHost));
+        const DevState* st = reinterpret_cast<const DevState*>(buf.data());
+        if (st->step < n) throw Err("fewer steps applied than requested");
+        for (int i = 0; i < n; ++i) host_dst[i] = st->cost_hist[(st->step - n + i) % kCostHist];
+        if (last_step) *last_step = st->step;
+    });
+}
+
+int avae_eval_cost(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, float* cost_host, void* stream) {
+    return guarded(h, [&] {
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x6576616cull /*eval*/, s);
+        const WorkItem* di = h->at<WorkItem>(h->off_items);
+        if (h->g_eval && !h->timing) HIP_OK(hipGraphLaunch(h->g_eval, s));
+        else { run_launches(h, h->fwd, di, s); run_launches(h, std::vector<Launch>{h->cost_only}, di, s); }
+        fetch_cost(h, cost_host, false, s);
+    });
+}
+
+static void run_inference(avae_handle* h, int m, bool enc, int rows, hipStream_t s) {
+    build_inference(h, m, enc, rows);
+    avae_handle::Inf& inf = enc ? h->inf_enc[m] : h->inf_dec[m];
+    // stream-ordered upload: earlier launches that read the old table have completed before it lands
+    HIP_OK(hipMemcpyAsync(h->at<void>(inf.dev_off), inf.items.data(), inf.items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
+    run_launches(h, inf.launches, h->at<WorkItem>(inf.dev_off), s);
+}
+
+int avae_encode(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld, int32_t rows, float* mu_dev, float* logvar_dev, void* stream) {
+    return guarded(h, [&] {
+        if (m < 0 || m >= h->M) throw Err("modality index out of range");
+        if (rows < 0) throw Err("rows must be >= 0");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const Mod& md = h->mods[m];
+        const int ld = x_ld > 0 ? x_ld : md.n_in;
+        const size_t nzb = (size_t)h->nz * 4;
+        for (int r0 = 0; r0 < rows; r0 += h->B) {
+            const int n = std::min(h->B, rows - r0);
+            run_prep_single(h, x_dev + (size_t)r0 * ld, ld, n, md.n_in, md.X0, nullptr, 0, true, nullptr, 0x656e63ull, s);
+            run_inference(h, m, true, n, s);
+            if (mu_dev) copy_rows(mu_dev + (size_t)r0 * h->nz, nzb, h->at<float>(md.mulv), 2 * nzb, nzb, n, s);
+            if (logvar_dev) copy_rows(logvar_dev + (size_t)r0 * h->nz, nzb, h->at<float>(md.mulv) + h->nz, 2 * nzb, nzb, n, s);
+        }
+    });
+}
+
+int avae_decode(avae_handle* h, int32_t m, const float* z_dev, int32_t rows, float* xhat_dev, void* stream) {
+    return guarded(h, [&] {
+        if (m < 0 || m >= h->M) throw Err("modality index out of range");
+        if (rows < 0) throw Err("rows must be >= 0");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const Mod& md = h->mods[m];
+        for (int r0 = 0; r0 < rows; r0 += h->B) {
+            const int n = std::min(h->B, rows - r0);
+            run_prep_single(h, z_dev + (size_t)r0 * h->nz, h->nz, n, h->nz, md.Z, nullptr, 0, false, nullptr, 0, s);
+            run_inference(h, m, false, n, s);
+            copy_rows(xhat_dev + (size_t)r0 * md.n_in, (size_t)md.n_in * 4, h->at<float>(md.out32), (size_t)md.ld32 * 4, (size_t)md.n_in * 4, n, s);
+        }
+    });
+}
+
+int avae_reconstruct(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld, const float* eps_dev, int32_t rows, float* xhat_dev, void* stream) {
+    return guarded(h, [&] {
+        if (m < 0 || m >= h->M) throw Err("modality index out of range");
+        if (rows < 0) throw Err("rows must be >= 0");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const Mod& md = h->mods[m];
+        const int ld = x_ld > 0 ? x_ld : md.n_in;
+        for (int r0 = 0; r0 < rows; r0 += h->B) {
+            const int n = std::min(h->B, rows - r0);
+            // a fresh eps per call and per modality, as each sess.run of the reference draws one (vae_assoc.py:423-424)
+            run_prep_single(h, x_dev + (size_t)r0 * ld, ld, n, md.n_in, md.X0, nullptr, 0, true,
+                            eps_dev ? eps_dev + (size_t)r0 * h->nz : nullptr,
+                            0x7265636full + ((unsigned long long)m << 40) + ((unsigned long long)(r0 / h->B) << 44), s);
+            run_inference(h, m, true, n, s);
+            run_inference(h, m, false, n, s);
+            copy_rows(xhat_dev + (size_t)r0 * md.n_in, (size_t)md.n_in * 4, h->at<float>(md.out32), (size_t)md.ld32 * 4, (size_t)md.n_in * 4, n, s);
+        }
+    });
+}
+
+// ---- checkpoint: "AVAECKPT" | u32 version | u32 n_mod | u32 n_z | per modality {n_input, L, hs[L]} | u64 P | i64 step | theta | m | v
+int avae_save(avae_handle* h, const char* path) {
+    return guarded(h, [&] {
+        std::vector<float> I, th(h->P_flat), mm(h->P_flat), vv(h->P_flat);
+        master_to_host(h, h->off_theta, I); convert_params<false>(h, th.data(), I.data());
+        master_to_host(h, h->off_m, I); convert_params<false>(h, mm.data(), I.data());
+        master_to_host(h, h->off_v, I); convert_params<false>(h, vv.data(), I.data());
+        long long step = 0;
+        HIP_OK(hipMemcpy(&step, &h->state()->step, sizeof(step), hipMemcpyDeviceToHost));
+        FILE* f = std::fopen(path, "wb");
+        if (!f) throw Err(std::string("cannot open for writing: ") + path);
+        auto w32 = [&](uint32_t v) { std::fwrite(&v, 4, 1, f); };
+        std::fwrite("AVAECKPT", 1, 8, f);
+        w32(1); w32((uint32_t)h->M); w32((uint32_t)h->nz);
+        for (const Mod& md : h->mods) { w32((uint32_t)md.n_in); w32((uint32_t)md.L); for (int x : md.hs) w32((uint32_t)x); }
+        uint64_t P = h->P_flat; std::fwrite(&P, 8, 1, f);
+        int64_t st = step; std::fwrite(&st, 8, 1, f);
+        bool ok = std::fwrite(th.data(), 4, P, f) == P && std::fwrite(mm.data(), 4, P, f) == P && std::fwrite(vv.data(), 4, P, f) == P;
+        ok = (std::fclose(f) == 0) && ok;
+        if (!ok) throw Err(std::string("short write: ") + path);
+    });
+}
+
+int avae_load(avae_handle* h, const char* path) {
+    return guarded(h, [&] {
+        FILE* f = std::fopen(path, "rb");
+        if (!f) throw Err(std::string("cannot open for reading: ") + path);
+        std::vector<float> th, mm, vv;
+        int64_t st = 0;
+        try {
+            char magic[8];
+            auto r32 = [&]() { uint32_t v = 0; if (std::fread(&v, 4, 1, f) != 1) throw Err("truncated checkpoint"); return v; };
+            if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "AVAECKPT", 8) != 0) throw Err("not an AVAE checkpoint");
+            if (r32() != 1) throw Err("unsupported checkpoint version");
+            if ((int)r32() != h->M || (int)r32() != h->nz) throw Err("checkpoint architecture mismatch (modalities / n_z)");
+            for (const Mod& md : h->mods) {
+                if ((int)r32() != md.n_in || (int)r32() != md.L) throw Err("checkpoint architecture mismatch (n_input / depth)");
+                for (int x : md.hs) if ((int)r32() != x) throw Err("checkpoint architecture mismatch (hidden width)");
+            }
+            uint64_t P = 0;
+            if (std::fread(&P, 8, 1, f) != 1 || P != h->P_flat) throw Err("checkpoint parameter count mismatch");
+            if (std::fread(&st, 8, 1, f) != 1) throw Err("truncated checkpoint");
+            th.resize(P); mm.resize(P); vv.resize(P);
+            if (std::fread(th.data(), 4, P, f) != P || std::fread(mm.data(), 4, P, f) != P || std::fread(vv.data(), 4, P, f) != P)
+                throw Err("truncated checkpoint");
+        } catch (...) { std::fclose(f); throw; }
+        std::fclose(f);
+        std::vector<float> I(h->P_int, 0.0f);
+        convert_params<true>(h, th.data(), I.data()); host_to_master(h, h->off_theta, I);
+        std::fill(I.begin(), I.end(), 0.0f); convert_params<true>(h, mm.data(), I.data()); host_to_master(h, h->off_m, I);
+        std::fill(I.begin(), I.end(), 0.0f); convert_params<true>(h, vv.data(), I.data()); host_to_master(h, h->off_v, I);
+        long long step = st;
+        HIP_OK(hipMemcpy(&h->state()->step, &step, sizeof(step), hipMemcpyHostToDevice));
+        run_adam(h, 1, nullptr);
+        HIP_OK(hipDeviceSynchronize());
+    });
+}
+
+int avae_synchronize(avae_handle* h) {
+    return guarded(h, [&] { HIP_OK(hipDeviceSynchronize()); });
+}
+
+int avae_timing_enable(avae_handle* h, int32_t on) {
+    return guarded(h, [&] {
+        HIP_OK(hipDeviceSynchronize());
+        for (TimingRec& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        h->trecs.clear();
+        h->timing = on != 0;
+    });
+}
+
+// one line per launch name: "<name> <calls> <avg_ms> <min_ms>\n"
+int avae_timing_report(avae_handle* h, char* buf, size_t buf_bytes) {
+    return guarded(h, [&] {
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<double> sum(h->tnames.size(), 0.0), mn(h->tnames.size(), 1e30);
+        std::vector<long> cnt(h->tnames.size(), 0);
+        for (TimingRec& r : h->trecs) {
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, r.a, r.b));
+            sum[r.launch_name] += ms; cnt[r.launch_name] += 1; mn[r.launch_name] = std::min(mn[r.launch_name], (double)ms);
+        }
+        std::string out;
+        for (size_t i = 0; i < h->tnames.size(); ++i) {
+            if (!cnt[i]) continue;
+            char line[256];
+            std::snprintf(line, sizeof(line), "%s %ld %.6f %.6f\n", h->tnames[i].c_str(), cnt[i], sum[i] / cnt[i], mn[i]);
+            out += line;
+        }
+        if (!buf || buf_bytes == 0) throw Err("null buffer");
+        std::snprintf(buf, buf_bytes, "%s", out.c_str());
+    });
+}
+
+int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t max_floats, size_t* n_floats) {
+    return guarded(h, [&] {
+        std::string n(name ? name : "");
+        const void* src = nullptr;
+        size_t cnt = 0;
+        if (n == "eps") { src = h->at<void>(h->off_eps); cnt = (size_t)h->B * h->nz; }
+        else if (n.rfind("mulv", 0) == 0 || n.rfind("g0_", 0) == 0) {
+            const bool g0 = n[0] == 'g';
+            const int m = std::atoi(n.c_str() + (g0 ? 3 : 4));
+            if (m < 0 || m >= h->M) throw Err("debug_fetch: modality out of range");
+            src = h->at<void>(g0 ? h->mods[m].g0 : h->mods[m].mulv); cnt = (size_t)h->B * 2 * h->nz;
+        } else throw Err("debug_fetch: unknown tensor " + n);
+        if (cnt > max_floats) throw Err("debug_fetch: destination too small");
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(host_dst, src, cnt * 4, hipMemcpyDeviceToHost));
+        if (n_floats) *n_floats = cnt;
+    });
+}
+
+}  // extern "C"

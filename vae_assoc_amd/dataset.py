@@ -1,0 +1,66 @@
+"""Data containers with the reference's batching semantics (/root/reference/dataset.py).
+
+``DataSet.next_batch`` (:22-43): sequential slices; when a slice would run past the end the
+data are reshuffled with ``np.random.shuffle`` and the epoch restarts at 0 -- the tail of the
+old order is discarded.  ``construct_datasets`` (:45-72): optional shuffle, then split at
+int((1-val-test)*N) and int((1-test)*N).  The reference's labelled path is broken (it never
+sets ``_num_examples`` when labels are given, :8-15, and slices labels wrongly at :65); here
+labels simply work.
+"""
+import numpy as np
+
+
+class DataSets(object):
+    pass
+
+
+class DataSet(object):
+    def __init__(self, data, labels=None):
+        if labels is not None:
+            assert data.shape[0] == labels.shape[0], (
+                'data.shape: %s labels.shape: %s' % (data.shape, labels.shape))
+        self._num_examples = data.shape[0]
+        self._data = data
+        self._labels = labels
+        self._epochs_completed = 0
+        self._index_in_epoch = 0
+
+    def next_batch(self, batch_size):
+        """Return the next `batch_size` examples from this data set."""
+        start = self._index_in_epoch
+        self._index_in_epoch += batch_size
+        if self._index_in_epoch > self._num_examples:
+            self._epochs_completed += 1          # finished epoch
+            perm = np.arange(self._num_examples)
+            np.random.shuffle(perm)              # shuffle the data
+            self._data = self._data[perm]
+            if self._labels is not None:
+                self._labels = self._labels[perm]
+            start = 0                            # start next epoch
+            self._index_in_epoch = batch_size
+            assert batch_size <= self._num_examples
+        end = self._index_in_epoch
+        if self._labels is not None:
+            return self._data[start:end], self._labels[start:end]
+        return self._data[start:end], None
+
+
+def construct_datasets(data, labels=None, shuffle=True, validation_ratio=.1, test_ratio=.1):
+    data_sets = DataSets()
+    if shuffle:
+        perm = np.arange(data.shape[0])
+        np.random.shuffle(perm)
+        data_shuffled = data[perm]
+        labels_shuffled = labels[perm] if labels is not None else None
+    else:
+        data_shuffled = data
+        labels_shuffled = labels
+    n = data_shuffled.shape[0]
+    test_start_idx = int((1 - test_ratio) * n)
+    validation_start_idx = int((1 - validation_ratio - test_ratio) * n)
+    lab = (lambda a, b: labels_shuffled[a:b]) if labels is not None else (lambda a, b: None)
+    data_sets.train = DataSet(data_shuffled[:validation_start_idx, :], lab(0, validation_start_idx))
+    data_sets.validation = DataSet(data_shuffled[validation_start_idx:test_start_idx, :],
+                                   lab(validation_start_idx, test_start_idx))
+    data_sets.test = DataSet(data_shuffled[test_start_idx:, :], lab(test_start_idx, n))
+    return data_sets

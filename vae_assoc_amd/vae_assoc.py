@@ -1,0 +1,460 @@
+"""Drop-in host side of the associative VAE: the reference's Python surface over libavae.
+
+Mirrors /root/reference/vae_assoc.py: class ``AssocVariationalAutoEncoder`` (:20-463) with
+``partial_fit / evaluate_cost / transform / generate / reconstruct / save_model / restore_model``
+and the module function ``train`` (:498-583), same argument names, defaults and error behaviour.
+Everything numerical happens in hand-written gfx950 kernels behind the C ABI of
+include/avae.h; PyTorch-ROCm tensors only hold device memory.  There is no CPU path.
+
+Deliberate, documented differences from the reference:
+  * ``transfer_fct`` is a name ('relu', 'softplus', ...) or any callable whose ``__name__`` is
+    one (``tf.nn.relu`` would qualify); the reference passes TF callables (:26,:502).
+  * weights are drawn with NumPy (TF's RNG stream is not reproducible); same distribution as
+    ``xavier_init`` (:11-18), biases zero.
+  * ``partial_fit`` / ``evaluate_cost`` / ``reconstruct`` accept an optional explicit ``eps``
+    (the reference draws it inside the graph, :90); ``None`` uses the in-kernel Philox stream.
+  * network dicts may carry an extra key ``n_hidden`` (list) for more than two hidden layers.
+  * ``hidden_conv=True`` (conv/deconv branch, :169-210,:249-291) raises: not built yet.
+"""
+import ctypes as C
+import datetime
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _capi
+from .parallel import GradSync
+
+_ARCH_KEYS = ("scope", "hidden_conv", "n_hidden_recog_1", "n_hidden_recog_2",
+              "n_hidden_gener_1", "n_hidden_gener_2", "n_input", "n_z")
+
+
+def xavier_init(fan_in, fan_out, constant=1, rng=None):
+    """Xavier initialisation of network weights (reference vae_assoc.py:11-18), as float32 NumPy."""
+    low = -constant * np.sqrt(6.0 / (fan_in + fan_out))
+    high = constant * np.sqrt(6.0 / (fan_in + fan_out))
+    rng = np.random if rng is None else rng
+    return rng.uniform(low, high, size=(fan_in, fan_out)).astype(np.float32)
+
+
+def _act_name(transfer_fct):
+    if transfer_fct is None:
+        return "identity"
+    name = transfer_fct if isinstance(transfer_fct, str) else getattr(transfer_fct, "__name__", str(transfer_fct))
+    name = name.lower()
+    if name not in _capi.ACT_IDS:
+        raise ValueError("unsupported transfer_fct %r (supported: %s)" % (transfer_fct, sorted(_capi.ACT_IDS)))
+    return name
+
+
+def hidden_sizes(na):
+    """Encoder widths of one modality.  The MLP decoder reuses them: the reference sizes its
+    generator from n_hidden_recog_* and ignores n_hidden_gener_* (vae_assoc.py:257,280,293,299)."""
+    if na.get("n_hidden") is not None:
+        return [int(h) for h in na["n_hidden"]]
+    return [int(na["n_hidden_recog_1"]), int(na["n_hidden_recog_2"])]
+
+
+def layer_shapes(na):
+    """Flat-parameter layout of one modality in the reference's variable-creation order
+    (vae_assoc.py:185-215,257-300): [(name, shape), ...]."""
+    hs = hidden_sizes(na)
+    n_in, n_z = int(na["n_input"]), int(na["n_z"])
+    shapes, prev = [], n_in
+    for i, h in enumerate(hs):
+        shapes += [("enc_W%d" % (i + 1), (prev, h)), ("enc_b%d" % (i + 1), (h,))]
+        prev = h
+    shapes += [("enc_Wmu", (prev, n_z)), ("enc_bmu", (n_z,)), ("enc_Wsig", (prev, n_z)), ("enc_bsig", (n_z,))]
+    prev = n_z
+    for i, h in enumerate(hs):
+        shapes += [("dec_W%d" % (i + 1), (prev, h)), ("dec_b%d" % (i + 1), (h,))]
+        prev = h
+    shapes += [("dec_Wout", (prev, n_in)), ("dec_bout", (n_in,))]
+    return shapes
+
+
+class AssocVariationalAutoEncoder(object):
+    """Associative VAE over M sensory modalities, trained on one MI355X (or one per rank).
+
+    Same constructor signature as the reference (vae_assoc.py:26-27); keyword-only extras:
+      compute_dtype  'bf16' (default: bf16 MFMA operands, fp32 accumulate/loss/Adam) or 'fp32'
+      device         torch device / ordinal (default: current CUDA(HIP) device)
+      seed           seeds the NumPy weight draw and the in-kernel eps generator
+      use_graph      replay the step as a captured hipGraph
+      data_parallel  True -> one replica per torch.distributed rank, sample-sharded batch,
+                     one SUM all-reduce of the flat gradient per step (RCCL over xGMI)
+    """
+
+    def __init__(self, network_architectures, binary=True, transfer_fct="softplus", weights=1.0,
+                 assoc_lambda=1.0, learning_rate=0.001, batch_size=100, *, compute_dtype="bf16",
+                 device=None, seed=0, use_graph=True, data_parallel=False, process_group=None):
+        self.network_architectures = network_architectures
+        self.assoc_lambda = assoc_lambda
+        n_mod = len(network_architectures)
+        # check if binary data (vae_assoc.py:31-35)
+        if type(binary) is list:
+            assert len(binary) == n_mod
+            self.binary = binary
+        else:
+            self.binary = [binary] * n_mod
+        if type(weights) is list:              # :37-41
+            assert len(weights) == n_mod
+            self.weights = weights
+        else:
+            self.weights = [weights] * n_mod
+        self.transfer_fct = transfer_fct
+        self._act = _act_name(transfer_fct)
+        self.learning_rate = learning_rate
+        self.batch_size = int(batch_size)
+        self.n_z = int(network_architectures[0]["n_z"])       # :89
+        if n_mod > _capi.AVAE_MAX_MODALITIES:
+            raise ValueError("at most %d modalities" % _capi.AVAE_MAX_MODALITIES)
+        for na in network_architectures:
+            if int(na["n_z"]) != self.n_z:
+                raise ValueError("all modalities must share n_z (the reference builds one eps of modality 0's n_z, :89-91)")
+            if na.get("hidden_conv"):
+                raise NotImplementedError("hidden_conv=True (conv/deconv branch) is not built yet")
+        if compute_dtype not in _capi.DTYPE_IDS:
+            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        self.compute_dtype = compute_dtype
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("vae_assoc_amd needs a HIP device (MI355X / gfx950); there is no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self._sync = GradSync(process_group) if data_parallel else None
+        world = self._sync.world_size if self._sync else 1
+        rank = self._sync.rank if self._sync else 0
+
+        cfg = _capi.Config()
+        cfg.abi_version = _capi.AVAE_ABI_VERSION
+        cfg.n_modalities = n_mod
+        for m, na in enumerate(network_architectures):
+            hs = hidden_sizes(na)
+            if len(hs) > _capi.AVAE_MAX_HIDDEN:
+                raise ValueError("at most %d hidden layers" % _capi.AVAE_MAX_HIDDEN)
+            cfg.mod[m].n_input = int(na["n_input"])
+            cfg.mod[m].n_hidden_layers = len(hs)
+            for k, hsz in enumerate(hs):
+                cfg.mod[m].n_hidden[k] = hsz
+            cfg.mod[m].binary = 1 if self.binary[m] else 0
+            cfg.mod[m].weight = float(self.weights[m])
+            cfg.mod[m].hidden_conv = 0
+        cfg.n_z = self.n_z
+        cfg.batch_size = self.batch_size
+        cfg.batch_global = self.batch_size * world
+        cfg.row_offset = rank * self.batch_size
+        cfg.activation = _capi.ACT_IDS[self._act]
+        cfg.compute_dtype = _capi.DTYPE_IDS[compute_dtype]
+        cfg.device = self.device.index
+        cfg.use_graph = 1 if use_graph else 0
+        cfg.assoc_lambda = float(assoc_lambda)
+        cfg.learning_rate = float(learning_rate)
+        cfg.beta1 = cfg.beta2 = cfg.adam_eps = 0.0          # -> TF-1 AdamOptimizer defaults
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+        L = _capi.lib()
+        nbytes = C.c_size_t(0)
+        _capi.check(None, L.avae_workspace_bytes(C.byref(cfg), C.byref(nbytes)), "avae_workspace_bytes")
+        # PyTorch is the device allocator: one uint8 tensor holds the whole replica state
+        self._ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+        base = self._ws.data_ptr()
+        self._ws_off = (-base) % 256
+        cfg.workspace = base + self._ws_off
+        cfg.workspace_bytes = nbytes.value
+        self._cfg = cfg
+        h = C.c_void_p()
+        torch.cuda.synchronize(self.device)
+        _capi.check(None, L.avae_create(C.byref(cfg), C.byref(h)), "avae_create")
+        self._h = h
+        self._L = L
+        n = C.c_size_t(0)
+        _capi.check(h, L.avae_param_count(h, C.byref(n)), "avae_param_count")
+        self.n_params = n.value
+        gp, gn = C.c_void_p(), C.c_size_t(0)
+        _capi.check(h, L.avae_grad_buffer(h, C.byref(gp), C.byref(gn)), "avae_grad_buffer")
+        goff = gp.value - base
+        self._grad_view = self._ws[goff:goff + 4 * gn.value].view(torch.float32)
+
+        # initial weights: xavier-uniform, zero biases (vae_assoc.py:185-215,257-300)
+        rng = np.random.RandomState(int(seed) & 0x7FFFFFFF)
+        flat = []
+        for na in network_architectures:
+            for _, shp in layer_shapes(na):
+                flat.append(xavier_init(shp[0], shp[1], rng=rng).reshape(-1) if len(shp) == 2
+                            else np.zeros(shp, dtype=np.float32))
+        self.set_params(np.concatenate(flat))
+
+    # ------------------------------------------------------------------ plumbing
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.avae_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, cols):
+        """-> (float32 device tensor [rows, cols] with unit column stride, was_numpy)."""
+        was_np = not torch.is_tensor(a)
+        t = torch.as_tensor(np.asarray(a, dtype=np.float32) if was_np else a)
+        if t.dim() != 2 or t.shape[1] != cols:
+            raise ValueError("expected a [rows, %d] array, got %s" % (cols, tuple(t.shape)))
+        t = t.to(device=self.device, dtype=torch.float32)
+        if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < cols):
+            t = t.contiguous()
+        return t, was_np
+
+    def _batch_args(self, X, eps):
+        assert len(X) == len(self.network_architectures)
+        ts = []
+        for x, na in zip(X, self.network_architectures):
+            t, _ = self._dev(x, int(na["n_input"]))
+            if t.shape[0] != self.batch_size:
+                # the reference's eps has static shape (batch_size, n_z): every path through z
+                # needs exactly batch_size rows (vae_assoc.py:90)
+                raise ValueError("expected %d rows (batch_size), got %d" % (self.batch_size, t.shape[0]))
+            ts.append(t)
+        ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        lds = (C.c_int32 * len(ts))(*[t.stride(0) if t.shape[0] > 1 else t.shape[1] for t in ts])
+        e = None
+        if eps is not None:
+            e, _ = self._dev(eps, self.n_z)
+            if e.shape[0] != self.batch_size:
+                raise ValueError("eps must be [batch_size, n_z]")
+            e = e.contiguous()
+        return ts, ptrs, lds, e
+
+    def get_params(self):
+        out = np.empty(self.n_params, dtype=np.float32)
+        _capi.check(self._h, self._L.avae_get_params(self._h, out.ctypes.data_as(C.c_void_p)), "avae_get_params")
+        return out
+
+    def set_params(self, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float32).reshape(-1)
+        if flat.size != self.n_params:
+            raise ValueError("expected %d parameters, got %d" % (self.n_params, flat.size))
+        _capi.check(self._h, self._L.avae_set_params(self._h, flat.ctypes.data_as(C.c_void_p)), "avae_set_params")
+
+    def get_grads(self):
+        out = np.empty(self.n_params, dtype=np.float32)
+        _capi.check(self._h, self._L.avae_get_grads(self._h, out.ctypes.data_as(C.c_void_p)), "avae_get_grads")
+        return out
+
+    def get_opt_state(self):
+        m = np.empty(self.n_params, dtype=np.float32)
+        v = np.empty(self.n_params, dtype=np.float32)
+        step = C.c_int64(0)
+        _capi.check(self._h, self._L.avae_get_opt_state(self._h, m.ctypes.data_as(C.c_void_p),
+                                                        v.ctypes.data_as(C.c_void_p), C.byref(step)), "avae_get_opt_state")
+        return m, v, step.value
+
+    def cost_history(self, n):
+        out = np.empty(n, dtype=np.float32)
+        last = C.c_int64(0)
+        _capi.check(self._h, self._L.avae_cost_history(self._h, n, out.ctypes.data_as(C.c_void_p), C.byref(last)),
+                    "avae_cost_history")
+        return out
+
+    def synchronize(self):
+        _capi.check(self._h, self._L.avae_synchronize(self._h), "avae_synchronize")
+
+    # ------------------------------------------------------------------ data-parallel seam (parallel.py protocol)
+    def _backward(self, X, eps=None):
+        ts, ptrs, lds, e = self._batch_args(X, eps)
+        _capi.check(self._h, self._L.avae_step_backward(self._h, ptrs, lds, e.data_ptr() if e is not None else None,
+                                                        self._stream()), "avae_step_backward")
+
+    def _grad_tensor(self):
+        return self._grad_view
+
+    def _apply(self, want_cost=True):
+        cost = C.c_float(0.0)
+        _capi.check(self._h, self._L.avae_step_apply(self._h, C.byref(cost) if want_cost else None, self._stream()),
+                    "avae_step_apply")
+        return cost.value if want_cost else None
+
+    # ------------------------------------------------------------------ reference surface
+    def partial_fit(self, X, eps=None, return_cost=True):
+        """Train model based on mini-batch of input data.  Return cost of mini-batch.
+        (reference vae_assoc.py:378-386).  ``return_cost=False`` skips the host synchronise;
+        the cost stays retrievable through ``cost_history``."""
+        if self._sync is not None and self._sync.world_size > 1:
+            self._backward(X, eps)
+            self._sync.all_reduce_(self._grad_view)
+            return self._apply(return_cost)
+        ts, ptrs, lds, e = self._batch_args(X, eps)
+        cost = C.c_float(0.0)
+        _capi.check(self._h, self._L.avae_train_step(self._h, ptrs, lds, e.data_ptr() if e is not None else None,
+                                                     C.byref(cost) if return_cost else None, self._stream()),
+                    "avae_train_step")
+        return cost.value if return_cost else None
+
+    def evaluate_cost(self, X, eps=None):
+        """reference vae_assoc.py:388-391 (forward + loss with a fresh eps, no update)."""
+        ts, ptrs, lds, e = self._batch_args(X, eps)
+        cost = C.c_float(0.0)
+        _capi.check(self._h, self._L.avae_eval_cost(self._h, ptrs, lds, e.data_ptr() if e is not None else None,
+                                                    C.byref(cost), self._stream()), "avae_eval_cost")
+        c = cost.value
+        if self._sync is not None and self._sync.world_size > 1:
+            c = self._sync.sum_scalar(c, self.device)
+        return c
+
+    def _encode(self, m, x, want_logvar=False):
+        t, was_np = self._dev(x, int(self.network_architectures[m]["n_input"]))
+        rows = t.shape[0]
+        mu = torch.empty((rows, self.n_z), dtype=torch.float32, device=self.device)
+        lv = torch.empty_like(mu) if want_logvar else None
+        if rows:
+            _capi.check(self._h, self._L.avae_encode(self._h, m, t.data_ptr(), t.stride(0) if rows > 1 else t.shape[1], rows,
+                                                     mu.data_ptr(), lv.data_ptr() if want_logvar else None,
+                                                     self._stream()), "avae_encode")
+        conv = (lambda a: a.cpu().numpy()) if was_np else (lambda a: a)
+        return (conv(mu), conv(lv)) if want_logvar else conv(mu)
+
+    def transform(self, X, sens_idx=None):
+        """Transform data by mapping it into the latent space (posterior means only).
+        ``sens_idx`` is None (X = list over modalities) or an integer (X = one array)
+        (reference vae_assoc.py:393-403)."""
+        if sens_idx is None:
+            return [self._encode(m, x) for m, x in enumerate(X)]
+        assert sens_idx < len(self.network_architectures)
+        return self._encode(sens_idx, X)
+
+    def generate(self, z_mu=None):
+        """Generate data by sampling from latent space: decoder only, z fed directly; returns the
+        list of per-modality decoder means.  ``None`` draws z from the prior with NumPy's global
+        RNG, batch_size rows (reference vae_assoc.py:405-419)."""
+        if z_mu is None:
+            z_mu = np.random.normal(size=(self.batch_size, self.n_z))
+        z, was_np = self._dev(z_mu, self.n_z)
+        z = z.contiguous()
+        rows = z.shape[0]
+        outs = []
+        for m, na in enumerate(self.network_architectures):
+            o = torch.empty((rows, int(na["n_input"])), dtype=torch.float32, device=self.device)
+            if rows:
+                _capi.check(self._h, self._L.avae_decode(self._h, m, z.data_ptr(), rows, o.data_ptr(), self._stream()),
+                            "avae_decode")
+            outs.append(o.cpu().numpy() if was_np else o)
+        return outs
+
+    def reconstruct(self, X, eps=None):
+        """Use VAE to reconstruct given data: encode -> sample z -> decode, per modality with its
+        own eps draw as each sess.run of the reference makes one (vae_assoc.py:421-425).
+        ``eps`` may be a list with one [rows, n_z] array per modality."""
+        outs = []
+        for m, (x, na) in enumerate(zip(X, self.network_architectures)):
+            t, was_np = self._dev(x, int(na["n_input"]))
+            rows = t.shape[0]
+            e = None
+            if eps is not None:
+                e, _ = self._dev(eps[m], self.n_z)
+                e = e.contiguous()
+                assert e.shape[0] == rows
+            o = torch.empty((rows, int(na["n_input"])), dtype=torch.float32, device=self.device)
+            if rows:
+                _capi.check(self._h, self._L.avae_reconstruct(self._h, m, t.data_ptr(), t.stride(0) if rows > 1 else t.shape[1],
+                                                              e.data_ptr() if e is not None else None, rows, o.data_ptr(),
+                                                              self._stream()), "avae_reconstruct")
+            outs.append(o.cpu().numpy() if was_np else o)
+        return outs
+
+    def save_model(self, fname=None):
+        """reference vae_assoc.py:427-435 (default name: timestamp + batch size)."""
+        if fname is None:
+            ts = time.time()
+            ckpt_fname = 'vae_assoc_' + datetime.datetime.fromtimestamp(ts).strftime('%Y_%m_%d_%H_%M_%S') \
+                + '_batchsize_{}.ckpt'.format(self.batch_size)
+        else:
+            ckpt_fname = fname
+        print('Saving model to {}...'.format(ckpt_fname))
+        _capi.check(self._h, self._L.avae_save(self._h, os.fsencode(ckpt_fname)), "avae_save")
+        return
+
+    def restore_model(self, folder=None, fname=None):
+        """reference vae_assoc.py:437-463: newest-listed *.ckpt of ``folder`` ('output' by default)
+        unless ``fname`` is given; every failure prints and returns, nothing raises."""
+        model_folder = 'output' if folder is None else folder
+        if os.path.isdir(model_folder) and os.path.exists(model_folder):
+            if fname is None:
+                files = [f for f in os.listdir(model_folder) if f.endswith('.ckpt')]
+                if not files:
+                    print('No valid model file.')
+                    return
+                model_file = files[-1]
+            else:
+                model_file = fname
+            path = os.path.join(model_folder, model_file)
+            if os.path.exists(path):
+                print('Loading {}...'.format(path))
+                rc = self._L.avae_load(self._h, os.fsencode(path))
+                if rc != 0:
+                    print('Invalid or non-exist model file. ({})'.format(self._L.avae_last_error(self._h).decode()))
+            else:
+                print('Invalid or non-exist model file.')
+        else:
+            print('Invalid or non-exist model folder.')
+        return
+
+
+def train(data_sets, network_architectures, binary=True, weights=1.0, assoc_lambda=1e-5, learning_rate=0.001,
+          batch_size=100, training_epochs=10, display_step=5, early_stop=False, **model_kwargs):
+    """Epoch/minibatch loop of the reference (vae_assoc.py:498-583): relu transfer (:502), column
+    split of the [N, sum n_input] matrix (:510,:543), optional validation early stop (:520-537),
+    ``avg_cost_hist`` = running within-epoch sum appended per batch (:576-577).
+
+    The batch matrix is uploaded once per step and split into modalities on the device by
+    pointer offset + row stride (no per-modality copies); per-step costs are read back once per
+    epoch from the device-side history, so the hot loop never synchronises."""
+    vae_assoc = AssocVariationalAutoEncoder(network_architectures, binary, transfer_fct="relu", weights=weights,
+                                            assoc_lambda=assoc_lambda, learning_rate=learning_rate,
+                                            batch_size=batch_size, **model_kwargs)
+    n_samples = data_sets.train._data.shape[0]
+    sens_indices = np.concatenate([[0], np.cumsum([na["n_input"] for na in network_architectures])])
+    n_mod = len(network_architectures)
+    avg_cost_hist = []
+    valid_cost = None
+    dev = vae_assoc.device
+    hist_cap = 4096
+
+    def seg(batch_xs):
+        t = torch.as_tensor(np.ascontiguousarray(batch_xs, dtype=np.float32)).to(dev)
+        return [t[:, sens_indices[k]:sens_indices[k + 1]] for k in range(n_mod)]
+
+    for epoch in range(training_epochs):
+        avg_cost = 0.
+        total_batch = int(n_samples / batch_size)
+        if early_stop:
+            if epoch % early_stop == 0:
+                curr_valid_cost = 0
+                n_valid_batches = int(data_sets.validation._data.shape[0] / batch_size)
+                for i in range(n_valid_batches):
+                    batch_xs, _ = data_sets.validation.next_batch(batch_size)
+                    curr_valid_cost += vae_assoc.evaluate_cost(seg(batch_xs)) / n_valid_batches
+                print("Validation cost=", "{:.9f}".format(curr_valid_cost))
+                if valid_cost is not None:
+                    if curr_valid_cost > valid_cost:
+                        print('Validation error increases. Early stop at epoch {} to prevent overfitting...'.format(epoch + 1))
+                        break
+                valid_cost = curr_valid_cost
+        done = 0
+        while done < total_batch:
+            chunk = min(hist_cap, total_batch - done)
+            for i in range(chunk):
+                batch_xs, _ = data_sets.train.next_batch(batch_size)
+                vae_assoc.partial_fit(seg(batch_xs), return_cost=False)
+            for cost in vae_assoc.cost_history(chunk):
+                avg_cost += float(cost) / n_samples * batch_size
+                avg_cost_hist.append(avg_cost)
+            done += chunk
+        if epoch % display_step == 0:
+            print("Epoch:", '%04d' % (epoch + 1), "cost=", "{:.9f}".format(avg_cost))
+    return vae_assoc, avg_cost_hist
