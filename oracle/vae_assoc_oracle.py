@@ -155,47 +155,82 @@ def act_name(transfer_fct):
     return name
 
 
+# ----------------------------------------------------------------------------- bf16 emulation
+def bf16_round(a):
+    """Round-to-nearest-even to bfloat16, returned as float64 (what v_cvt_pk_bf16_f32 does)."""
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    u = a32.view(np.uint32)
+    u2 = ((u + ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)) & np.uint32(0xFFFF0000)).astype(np.uint32)
+    return u2.view(np.float32).astype(np.float64).reshape(np.shape(a))
+
+
+# The HIP path with bf16 operands rounds exactly at these points (DESIGN.md "precision"):
+# GEMM inputs (x, weights AND biases -- the bias rides in the GEMM as an extra weight row),
+# every stored hidden activation, z, and every stored activation-gradient; products are
+# accumulated in fp32 and mu / lv / logits / losses / weight gradients / Adam stay fp32.
+# ``quant='bf16'`` reproduces that placement on the CPU so the bf16 kernels can be checked
+# tightly (same roundings -> same relu decisions); ``quant=None`` is the plain restatement.
+# Transfer-function derivatives are then taken from the STORED (rounded) output, as the kernels do.
+DACT_FROM_OUTPUT = {
+    "relu": lambda y: (y > 0).astype(y.dtype),
+    "softplus": lambda y: 1.0 - np.exp(-y),
+    "sigmoid": lambda y: y * (1.0 - y),
+    "tanh": lambda y: 1.0 - y * y,
+    "identity": lambda y: np.ones_like(y),
+}
+
+
+def _q(quant):
+    if quant is None:
+        return lambda a: a
+    if quant == "bf16":
+        return bf16_round
+    raise ValueError("quant must be None or 'bf16'")
+
+
 # ----------------------------------------------------------------------------- forward
-def encode(na, p, x, act):
+def encode(na, p, x, act, quant=None):
     """_recognition_network, MLP branch (vae_assoc.py:185-188,201-204,212-221)."""
     f, _ = ACT[act]
+    q = _q(quant)
     hs = hidden_sizes(na)
-    acts, pre = [x], []
-    h = x
+    h = q(x)
+    acts, pre = [h], []
     for i in range(len(hs)):
-        a = h @ p["enc_W%d" % (i + 1)] + p["enc_b%d" % (i + 1)]
-        h = f(a)
+        a = h @ q(p["enc_W%d" % (i + 1)]) + q(p["enc_b%d" % (i + 1)])
+        h = q(f(a))
         pre.append(a)
         acts.append(h)
-    mu = h @ p["enc_Wmu"] + p["enc_bmu"]
-    lv = h @ p["enc_Wsig"] + p["enc_bsig"]
+    mu = h @ q(p["enc_Wmu"]) + q(p["enc_bmu"])
+    lv = h @ q(p["enc_Wsig"]) + q(p["enc_bsig"])
     return mu, lv, {"acts": acts, "pre": pre}
 
 
-def decode(na, p, z, act, binary):
+def decode(na, p, z, act, binary, quant=None):
     """_generator_network, MLP branch (vae_assoc.py:257-260,280-283,293-303)."""
     f, _ = ACT[act]
+    q = _q(quant)
     hs = hidden_sizes(na)
-    acts, pre = [z], []
-    g = z
+    g = q(z)
+    acts, pre = [g], []
     for i in range(len(hs)):
-        a = g @ p["dec_W%d" % (i + 1)] + p["dec_b%d" % (i + 1)]
-        g = f(a)
+        a = g @ q(p["dec_W%d" % (i + 1)]) + q(p["dec_b%d" % (i + 1)])
+        g = q(f(a))
         pre.append(a)
         acts.append(g)
-    logits = g @ p["dec_Wout"] + p["dec_bout"]
+    logits = g @ q(p["dec_Wout"]) + q(p["dec_bout"])
     xhat = _sigmoid(logits) if binary else logits
     return xhat, {"acts": acts, "pre": pre, "logits": logits}
 
 
-def forward(archs, params, X, eps, binary, act):
+def forward(archs, params, X, eps, binary, act, quant=None):
     """_create_network (vae_assoc.py:78-119): ONE eps [B,n_z] shared by every modality (:90),
     z = mu + sqrt(exp(lv))*eps (:102-103)."""
     out = []
     for na, p, x, b in zip(archs, params, X, binary):
-        mu, lv, ec = encode(na, p, x, act)
+        mu, lv, ec = encode(na, p, x, act, quant)
         z = mu + np.sqrt(np.exp(lv)) * eps
-        xhat, dc = decode(na, p, z, act, b)
+        xhat, dc = decode(na, p, z, act, b, quant)
         out.append({"mu": mu, "lv": lv, "z": z, "xhat": xhat, "enc": ec, "dec": dc})
     return out
 
@@ -255,11 +290,16 @@ def shard_cost(archs, fw, X, binary, weights, assoc_lambda, batch_global):
 
 
 # ----------------------------------------------------------------------------- backward
-def backward(archs, params, fw, X, eps, binary, weights, assoc_lambda, act, batch_global=None):
+def backward(archs, params, fw, X, eps, binary, weights, assoc_lambda, act, batch_global=None, quant=None):
     """Analytic gradient of ``cost`` w.r.t. every parameter (what TF autodiff of
     vae_assoc.py:373-374 produces).  Formulas: SURVEY.md 8(a) row A5.  Mean terms carry
     1/batch_global, sum terms (Gaussian recon, assoc) carry 1."""
-    _, dact = ACT[act]
+    _, dact_pre = ACT[act]
+    q = _q(quant)
+    if quant is None:
+        dact = dact_pre
+    else:
+        dact = lambda a, y: DACT_FROM_OUTPUT[act](y)      # noqa: E731  (from the stored, rounded output)
     M = len(archs)
     B = X[0].shape[0]
     Bg = B if batch_global is None else batch_global
@@ -285,31 +325,32 @@ def backward(archs, params, fw, X, eps, binary, weights, assoc_lambda, act, batc
             dl = (w / Bg) * xr * (1 - xr) * (-x / (1e-3 + xr) + (1 - x) / (1e-3 + 1 - xr))
         else:   # d/dxhat of w * sum (x-xhat)^2 / 2
             dl = w * (xr - x)
+        dl = q(dl)
         dacts, dpre = f["dec"]["acts"], f["dec"]["pre"]
         g["dec_Wout"] = dacts[L].T @ dl
         g["dec_bout"] = dl.sum(0)
-        dg = dl @ p["dec_Wout"].T
+        dg = dl @ q(p["dec_Wout"]).T
         for i in range(L - 1, -1, -1):
-            da = dg * dact(dpre[i], dacts[i + 1])
+            da = q(dg * dact(dpre[i], dacts[i + 1]))
             g["dec_W%d" % (i + 1)] = dacts[i].T @ da
             g["dec_b%d" % (i + 1)] = da.sum(0)
-            dg = da @ p["dec_W%d" % (i + 1)].T
+            dg = da @ q(p["dec_W%d" % (i + 1)]).T
         dz = dg
         # reparameterisation: z = mu + exp(lv/2)*eps
-        gmu = dmu[m] + dz
-        glv = dlv[m] + dz * 0.5 * np.sqrt(np.exp(f["lv"])) * eps
+        gmu = q(dmu[m] + dz)
+        glv = q(dlv[m] + dz * 0.5 * np.sqrt(np.exp(f["lv"])) * eps)
         eacts, epre = f["enc"]["acts"], f["enc"]["pre"]
         g["enc_Wmu"] = eacts[L].T @ gmu
         g["enc_bmu"] = gmu.sum(0)
         g["enc_Wsig"] = eacts[L].T @ glv
         g["enc_bsig"] = glv.sum(0)
-        dh = gmu @ p["enc_Wmu"].T + glv @ p["enc_Wsig"].T
+        dh = gmu @ q(p["enc_Wmu"]).T + glv @ q(p["enc_Wsig"]).T
         for i in range(L - 1, -1, -1):
-            da = dh * dact(epre[i], eacts[i + 1])
+            da = q(dh * dact(epre[i], eacts[i + 1]))
             g["enc_W%d" % (i + 1)] = eacts[i].T @ da
             g["enc_b%d" % (i + 1)] = da.sum(0)
             if i > 0:
-                dh = da @ p["enc_W%d" % (i + 1)].T
+                dh = da @ q(p["enc_W%d" % (i + 1)]).T
         grads.append(g)
     return grads, {"dmu_direct": dmu, "dlv_direct": dlv}
 
@@ -335,7 +376,7 @@ class OracleAssocVAE(object):
 
     def __init__(self, network_architectures, binary=True, transfer_fct="softplus", weights=1.0,
                  assoc_lambda=1.0, learning_rate=0.001, batch_size=100, dtype=np.float64,
-                 seed=0, params_flat=None):
+                 seed=0, params_flat=None, quant=None):
         self.network_architectures = network_architectures
         self.assoc_lambda = assoc_lambda
         M = len(network_architectures)
@@ -353,6 +394,7 @@ class OracleAssocVAE(object):
         self.learning_rate = learning_rate
         self.batch_size = batch_size
         self.dtype = dtype
+        self.quant = quant                                # None, or 'bf16' = emulate the bf16-operand kernels
         self.n_z = int(network_architectures[0]["n_z"])   # :89
         self.rng = np.random.default_rng(seed)
         if params_flat is None:
@@ -382,7 +424,7 @@ class OracleAssocVAE(object):
     def cost_and_grads(self, X, eps, batch_global=None):
         X = self._cast(X)
         eps = self._eps(eps, X[0].shape[0])
-        fw = forward(self.network_architectures, self.params, X, eps, self.binary, self.act)
+        fw = forward(self.network_architectures, self.params, X, eps, self.binary, self.act, self.quant)
         if batch_global is None:
             cost = loss_terms(self.network_architectures, fw, X, self.binary, self.weights,
                               self.assoc_lambda)["cost"]
@@ -390,7 +432,7 @@ class OracleAssocVAE(object):
             cost = shard_cost(self.network_architectures, fw, X, self.binary, self.weights,
                               self.assoc_lambda, batch_global)
         grads, _ = backward(self.network_architectures, self.params, fw, X, eps, self.binary,
-                            self.weights, self.assoc_lambda, self.act, batch_global)
+                            self.weights, self.assoc_lambda, self.act, batch_global, self.quant)
         return cost, flatten_params(self.network_architectures, grads), fw
 
     def apply_gradients(self, gflat):
@@ -412,25 +454,25 @@ class OracleAssocVAE(object):
         """vae_assoc.py:388-391."""
         X = self._cast(X)
         eps = self._eps(eps, X[0].shape[0])
-        fw = forward(self.network_architectures, self.params, X, eps, self.binary, self.act)
+        fw = forward(self.network_architectures, self.params, X, eps, self.binary, self.act, self.quant)
         return float(loss_terms(self.network_architectures, fw, X, self.binary, self.weights,
                                 self.assoc_lambda)["cost"])
 
     def transform(self, X, sens_idx=None):
         """vae_assoc.py:393-403: posterior means only."""
         if sens_idx is None:
-            return [encode(na, p, np.asarray(x, dtype=self.dtype), self.act)[0]
+            return [encode(na, p, np.asarray(x, dtype=self.dtype), self.act, self.quant)[0]
                     for na, p, x in zip(self.network_architectures, self.params, X)]
         assert sens_idx < len(self.network_architectures)
         return encode(self.network_architectures[sens_idx], self.params[sens_idx],
-                      np.asarray(X, dtype=self.dtype), self.act)[0]
+                      np.asarray(X, dtype=self.dtype), self.act, self.quant)[0]
 
     def generate(self, z_mu=None):
         """vae_assoc.py:405-419: decoder only, z fed directly."""
         if z_mu is None:
             z_mu = np.random.normal(size=(self.batch_size, self.n_z))
         z_mu = np.asarray(z_mu, dtype=self.dtype)
-        return [decode(na, p, z_mu, self.act, b)[0]
+        return [decode(na, p, z_mu, self.act, b, self.quant)[0]
                 for na, p, b in zip(self.network_architectures, self.params, self.binary)]
 
     def reconstruct(self, X, eps=None):
@@ -439,10 +481,10 @@ class OracleAssocVAE(object):
         out = []
         for m, (na, p, x, b) in enumerate(zip(self.network_architectures, self.params, X, self.binary)):
             x = np.asarray(x, dtype=self.dtype)
-            mu, lv, _ = encode(na, p, x, self.act)
+            mu, lv, _ = encode(na, p, x, self.act, self.quant)
             e = self._eps(None if eps is None else eps[m], x.shape[0])
             z = mu + np.sqrt(np.exp(lv)) * e
-            out.append(decode(na, p, z, self.act, b)[0])
+            out.append(decode(na, p, z, self.act, b, self.quant)[0])
         return out
 
 

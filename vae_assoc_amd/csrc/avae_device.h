@@ -114,9 +114,14 @@ struct PrepArgs {
     unsigned long long stream_salt;   // distinguishes train / eval / reconstruct draws
 };
 
+// Diagnostic build only (-DAVAE_STAMPS): thread 0 of every block records s_memrealtime (100 MHz)
+// at kernel entry / after the item lookup / after the first staged tile / after the K loop / at
+// the end, plus s_memtime (shader clock) at entry and end.  No stamp executes in the product build.
+constexpr int kStampLaunches = 16, kStampBlocks = 512, kStampWords = 8;
+
 // launchers implemented in avae_kernels.hip
 void launch_grouped(int compute_dtype, int tile_cfg, const WorkItem* items, int n_items, int n_blocks,
-                    DevState* st, hipStream_t s);
+                    DevState* st, hipStream_t s, unsigned long long* stamps = nullptr, int launch_id = 0);
 void launch_adam(int compute_dtype, const AdamArgs& a, int n_blocks, hipStream_t s);
 void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s);
 void launch_fill(void* base, int elem_bytes, unsigned bits, long long start, long long stride, int count, hipStream_t s);

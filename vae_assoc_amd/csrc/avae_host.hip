@@ -84,7 +84,7 @@ struct avae_handle {
     std::vector<Mod> mods;
     size_t P_flat = 0, P_int = 0;            // flat API count, internal padded count (floats)
     size_t off_theta = 0, off_m = 0, off_v = 0, off_g = 0;   // byte offsets; g has P_int + 64 floats
-    size_t off_eps = 0, off_partial = 0, off_state = 0, off_items = 0, off_adam = 0, off_inf = 0;
+    size_t off_eps = 0, off_partial = 0, off_state = 0, off_items = 0, off_adam = 0, off_inf = 0, off_stamps = 0;
     int n_partial = 0;
     size_t ws_bytes = 0;
     unsigned char* ws = nullptr;
@@ -220,6 +220,9 @@ void plan_memory(avae_handle* h) {
     h->off_adam = b.take(n_adam * sizeof(AdamItem));
     h->off_inf = b.off;
     for (int m = 0; m < h->M; ++m) b.take(2 * ((size_t)h->mods[m].L + 1) * sizeof(WorkItem));
+#ifdef AVAE_STAMPS
+    h->off_stamps = b.take((size_t)kStampLaunches * kStampBlocks * kStampWords * 8);
+#endif
     h->ws_bytes = b.off;
 }
 
@@ -521,10 +524,16 @@ struct Timed {
     }
 };
 
-void run_launches(avae_handle* h, const std::vector<Launch>& ls, const WorkItem* dev_items, hipStream_t s) {
+void run_launches(avae_handle* h, const std::vector<Launch>& ls, const WorkItem* dev_items, hipStream_t s, int stamp_base = -1) {
+    int k = 0;
     for (const Launch& L : ls) {
         Timed t(h, s, L.name);
-        launch_grouped(h->cfg.compute_dtype, L.cfg, dev_items + L.first, L.count, L.blocks, h->state(), s);
+        unsigned long long* stamps = nullptr;
+#ifdef AVAE_STAMPS
+        if (stamp_base >= 0) stamps = h->at<unsigned long long>(h->off_stamps);
+#endif
+        launch_grouped(h->cfg.compute_dtype, L.cfg, dev_items + L.first, L.count, L.blocks, h->state(), s, stamps, stamp_base + k);
+        ++k;
     }
 }
 
@@ -630,7 +639,7 @@ void init_device(avae_handle* h) {
         h->timing = false;
         h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, di, cs); run_launches(h, h->bwd, di, cs); });
         h->g_adam = capture(h, [&](hipStream_t cs) { run_adam(h, 0, cs); });
-        h->g_full = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, di, cs); run_launches(h, h->bwd, di, cs); run_adam(h, 0, cs); });
+        h->g_full = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, di, cs, 0); run_launches(h, h->bwd, di, cs, (int)h->fwd.size()); run_adam(h, 0, cs); });
         h->g_eval = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, di, cs); run_launches(h, std::vector<Launch>{h->cost_only}, di, cs); });
         h->timing = tsave;
     }
@@ -1010,6 +1019,9 @@ int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t m
         const void* src = nullptr;
         size_t cnt = 0;
         if (n == "eps") { src = h->at<void>(h->off_eps); cnt = (size_t)h->B * h->nz; }
+#ifdef AVAE_STAMPS
+        else if (n == "stamps") { src = h->at<void>(h->off_stamps); cnt = (size_t)kStampLaunches * kStampBlocks * kStampWords * 2; }
+#endif
         else if (n.rfind("mulv", 0) == 0 || n.rfind("g0_", 0) == 0) {
             const bool g0 = n[0] == 'g';
             const int m = std::atoi(n.c_str() + (g0 ? 3 : 4));

@@ -205,17 +205,30 @@ template <int BM, int BN> struct TileSmem {
 };
 
 template <typename CT, int BM, int BN>
-__global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict__ items, int n_items, DevState* st) {
+__global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict__ items, int n_items, DevState* st,
+                                                      unsigned long long* stamps, int launch_id) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[TileSmem<BM, BN>::kTotal];
     float* red = reinterpret_cast<float*>(smem + TileSmem<BM, BN>::kMain);
+#ifdef AVAE_STAMPS
+    unsigned long long sv[kStampWords] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define AVAE_STAMP(i) { __builtin_amdgcn_sched_barrier(0); sv[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
+#define AVAE_STAMP_FLUSH() { if (stamps && threadIdx.x == 0 && launch_id < kStampLaunches && blockIdx.x < kStampBlocks) { \
+        sv[6] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+        for (int i_ = 0; i_ < kStampWords; ++i_) stamps[((size_t)launch_id * kStampBlocks + blockIdx.x) * kStampWords + i_] = sv[i_]; } }
+    AVAE_STAMP(0)
+    sv[5] = __builtin_amdgcn_s_memtime();
+#else
+#define AVAE_STAMP(i)
+#define AVAE_STAMP_FLUSH()
+#endif
 
     const int bid = blockIdx.x;
     int it = 0;
     while (it + 1 < n_items && bid >= items[it + 1].tile_base) ++it;
     const WorkItem& w = items[it];
     const int t = bid - w.tile_base;
-    if (w.kind == K_LATENT) { latent_item(w, t, red); return; }
-    if (w.kind == K_COST) { cost_item(w, st, red); return; }
+    if (w.kind == K_LATENT) { latent_item(w, t, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
+    if (w.kind == K_COST) { cost_item(w, st, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
 
     constexpr int WM = BM / 2, WN = BN / 2;       // per-wave sub-tile (2x2 waves)
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -282,9 +295,11 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict
         }                                                                                              \
     }
 
+    AVAE_STAMP(1)
     AVAE_GLOAD(0)
     AVAE_SWRITE(0)
     __syncthreads();
+    AVAE_STAMP(2)
     for (int kt = 0; kt < nk - 1; ++kt) {
         AVAE_GLOAD(kt + 1)
         AVAE_COMPUTE(kt & 1)
@@ -293,6 +308,7 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict
     }
     AVAE_COMPUTE((nk - 1) & 1)
     __syncthreads();
+    AVAE_STAMP(3)
 #undef AVAE_GLOAD
 #undef AVAE_SWRITE
 #undef AVAE_COMPUTE
@@ -470,17 +486,19 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict
     } break;
     default: break;
     }
+    AVAE_STAMP(4)
+    AVAE_STAMP_FLUSH()
 }
 
 void launch_grouped(int compute_dtype, int tile_cfg, const WorkItem* items, int n_items, int n_blocks,
-                    DevState* st, hipStream_t s) {
+                    DevState* st, hipStream_t s, unsigned long long* stamps, int launch_id) {
     dim3 grid(n_blocks), block(kThreads);
     if (compute_dtype == AVAE_BF16) {
-        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<__bf16, 64, 64>), grid, block, 0, s, items, n_items, st);
-        else hipLaunchKernelGGL((k_grouped<__bf16, 128, 128>), grid, block, 0, s, items, n_items, st);
+        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<__bf16, 64, 64>), grid, block, 0, s, items, n_items, st, stamps, launch_id);
+        else hipLaunchKernelGGL((k_grouped<__bf16, 128, 128>), grid, block, 0, s, items, n_items, st, stamps, launch_id);
     } else {
-        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<float, 64, 64>), grid, block, 0, s, items, n_items, st);
-        else hipLaunchKernelGGL((k_grouped<float, 128, 128>), grid, block, 0, s, items, n_items, st);
+        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<float, 64, 64>), grid, block, 0, s, items, n_items, st, stamps, launch_id);
+        else hipLaunchKernelGGL((k_grouped<float, 128, 128>), grid, block, 0, s, items, n_items, st, stamps, launch_id);
     }
 }
 
