@@ -23,7 +23,7 @@ def main():
         shutil.rmtree(out)
     shutil.copytree(os.path.join(ROOT, "vae_assoc_amd"), pkg, ignore=shutil.ignore_patterns("*.so", "__pycache__"))
     src = [os.path.join(ROOT, "vae_assoc_amd", "csrc", f) for f in ("avae_kernels.hip", "avae_host.hip")]
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DAVAE_STAMPS"]
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DAVAE_STAMPS"] + (["-DAVAE_STAMPS_REPEAT"] if os.environ.get("REPEAT") else [])
                    + src + ["-o", os.path.join(pkg, "libavae.so")], check=True)
     import torch
     import bench
@@ -63,10 +63,14 @@ def main():
         g = s[gemm]
         def seg(a, b):
             return ((g[:, b] - g[:, a]).mean() / 100.0) if len(g) else 0.0
-        clk = ((s[:, 6] - s[:, 5]) / np.maximum(s[:, 4] - s[:, 0], 1)).mean() * 100.0
-        print("%-16s %6d %8.2f | %7.2f %7.2f %7.2f %7.2f | %8.2f %7.0f  gap_before=%.2f" % (
+        e1 = g[g[:, 6] > 0]
+        ep = "acc->lds %.2f pass1 %.2f rest %.2f" % (((e1[:, 5] - e1[:, 3]).mean() / 100.0), ((e1[:, 6] - e1[:, 5]).mean() / 100.0),
+                                                     ((e1[:, 4] - e1[:, 6]).mean() / 100.0)) if len(e1) else ""
+        if len(e1) and (e1[:, 7] > 0).any():
+            ep += " pass1-again %.2f" % ((e1[:, 7] - e1[:, 6]).mean() / 100.0)
+        print("%-16s %6d %8.2f | %7.2f %7.2f %7.2f %7.2f | %8.2f  gap_before=%.2f  %s" % (
             names[l] if l < len(names) else "L%d" % l, live.sum(), span, seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4),
-            (t0.max() - t0.min()) / 100.0, clk, gap))
+            (t0.max() - t0.min()) / 100.0, gap, ep))
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ constexpr int kMaxMod = 4;
 constexpr int kThreads = 256;          // 4 wavefronts of 64
 constexpr int kTileBytesK = 128;       // bytes of K per staged tile row: 64 bf16 or 32 f32
 constexpr int kRowAlign = 128;         // row counts of GEMM operands are padded to this (largest tile)
-constexpr int kLatentRows = 64;        // rows per latent work-item tile
+constexpr int kLatentRows = 16;        // rows per latent work-item tile (many small blocks: the item is latency-bound)
 constexpr int kCostHist = 4096;        // ring of per-step costs kept on the device
 
 // Work-item kinds.  All GEMM kinds compute C[M,N] = sum_k A[m][k] * B[n][k] with both operands
@@ -55,15 +55,28 @@ struct WorkItem {
     const void* aux1;
     const void* aux2;
     float* partial;          // cost partial slots
-    const float* mulv[kMaxMod];   // K_LATENT inputs  [B][2nz]
-    float* g0[kMaxMod];           // K_LATENT outputs [B][2nz]
-    float wts[kMaxMod];
+    const float* eps;        // K_LATENT: the step's eps [B][ldx]
+    float wts[kMaxMod];      // K_LATENT: per-modality cost weights
+    // K_LATENT reuses the pointer fields: [mu|lv] inputs of modality 0..3 = A, B, aux0, aux1;
+    // static-gradient outputs g0 of modality 0..3 = out0, out1, out2, aux2.
+    // K_COST: scale = lr, lambda = beta1, inv_bg = beta2 (it also publishes this step's Adam lr_t).
+};
+
+// One launch = up to kMaxItemsPerLaunch work items, passed BY VALUE in the kernel-argument
+// segment together with the first block index of every item: a workgroup finds and reads its item
+// without a chain of dependent loads from HBM, and no device-side table has to be kept in sync.
+constexpr int kMaxItemsPerLaunch = 12;
+struct LaunchArgs {
+    int n_items;
+    int base[kMaxItemsPerLaunch];
+    int pad[3];
+    WorkItem items[kMaxItemsPerLaunch];
 };
 
 struct DevState {
     long long step;          // number of applied Adam steps
     float last_cost;
-    float pad0;
+    float lr_t;              // lr*sqrt(1-b2^t)/(1-b1^t) of the step being applied (written by K_COST)
     float cost_hist[kCostHist];
 };
 
@@ -81,9 +94,11 @@ struct AdamItem {
     int pad;
 };
 
+constexpr int kMaxAdamItems = 80;      // kMaxMod * (2*AVAE_MAX_HIDDEN + 2)
 struct AdamArgs {
     const AdamItem* items;
     int n_items;
+    int base[kMaxAdamItems];           // first tile of every item (by value: no dependent scan through HBM)
     int mode;                // 0: Adam update; 1: refresh shadows from theta only
     float lr, beta1, beta2, eps;
     DevState* st;
@@ -107,7 +122,7 @@ struct PrepArgs {
     // eps
     const float* eps_src;          // nullable -> Philox
     float* eps_dst;                // nullable -> no eps work
-    int eps_rows, nz, eps_blocks;
+    int eps_rows, nz, eps_blocks, eps_ld;   // eps_ld = roundup(nz, 4): row stride of the internal eps buffer
     int row_offset;
     unsigned long long seed;
     const DevState* st;
@@ -120,7 +135,7 @@ struct PrepArgs {
 constexpr int kStampLaunches = 16, kStampBlocks = 512, kStampWords = 8;
 
 // launchers implemented in avae_kernels.hip
-void launch_grouped(int compute_dtype, int tile_cfg, const WorkItem* items, int n_items, int n_blocks,
+void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int n_blocks,
                     DevState* st, hipStream_t s, unsigned long long* stamps = nullptr, int launch_id = 0);
 void launch_adam(int compute_dtype, const AdamArgs& a, int n_blocks, hipStream_t s);
 void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s);

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -68,6 +69,7 @@ struct Mod {
 struct Launch {
     std::string name;
     int cfg = 0, first = 0, count = 0, blocks = 0;
+    LaunchArgs args{};
 };
 
 struct TimingRec { hipEvent_t a, b; int launch_name; };
@@ -80,11 +82,11 @@ struct avae_handle {
     std::string err;
     int es = 2, KU = 64;
     int B = 0, Bp = 0, ldB = 0;   // batch, batch padded to 128 rows, rup(batch, KU)
-    int nz = 0, M = 0;
+    int nz = 0, M = 0, ld_eps = 0;
     std::vector<Mod> mods;
     size_t P_flat = 0, P_int = 0;            // flat API count, internal padded count (floats)
     size_t off_theta = 0, off_m = 0, off_v = 0, off_g = 0;   // byte offsets; g has P_int + 64 floats
-    size_t off_eps = 0, off_partial = 0, off_state = 0, off_items = 0, off_adam = 0, off_inf = 0, off_stamps = 0;
+    size_t off_eps = 0, off_partial = 0, off_state = 0, off_items = 0, off_adam = 0, off_inf = 0, off_stamps = 0, off_latent = 0;
     int n_partial = 0;
     size_t ws_bytes = 0;
     unsigned char* ws = nullptr;
@@ -103,6 +105,7 @@ struct avae_handle {
     hipGraphExec_t g_full = nullptr, g_bwd = nullptr, g_adam = nullptr, g_eval = nullptr;
 
     bool timing = false;
+    bool debug_sync = false;
     std::vector<std::string> tnames;
     std::vector<TimingRec> trecs;
 
@@ -162,6 +165,7 @@ void plan_memory(avae_handle* h) {
     h->Bp = (int)rup(h->B, kRowAlign);
     h->ldB = (int)rup(h->B, h->KU);
     h->nz = c.n_z;
+    h->ld_eps = (int)rup(c.n_z, 4);
     h->M = c.n_modalities;
     const int KU = h->KU, es = h->es, Bp = h->Bp, ldB = h->ldB, nz = h->nz, B = h->B;
     Bump b;
@@ -190,11 +194,11 @@ void plan_memory(avae_handle* h) {
         md.dH = make_act(b, 2 * nz, false, Bp, ldB, KU, es);
         for (int k = 0; k < md.L; ++k) md.dD.push_back(make_act(b, md.hs[k], false, Bp, ldB, KU, es));
         md.dO = make_act(b, md.n_in, false, Bp, ldB, KU, es);
-        md.ld32 = (int)rup(md.n_in, 4);
+        md.ld32 = (int)rup(md.n_in, 8);      // multiple of the widest epilogue vector (8 elements)
         md.X32 = b.take((size_t)B * md.ld32 * 4);
         md.out32 = b.take((size_t)B * md.ld32 * 4);
         md.mulv = b.take((size_t)B * 2 * nz * 4);
-        md.g0 = b.take((size_t)B * 2 * nz * 4);
+        md.g0 = b.take((size_t)B * 3 * nz * 4);        // [g0mu | g0lv | dz/dlv factor]
         h->mods.push_back(std::move(md));
     }
     h->P_int = pint;
@@ -203,7 +207,7 @@ void plan_memory(avae_handle* h) {
     h->off_m = b.take(pint * 4);
     h->off_v = b.take(pint * 4);
     h->off_g = b.take((pint + 64) * 4);      // + cost slot (element P_int), padded
-    h->off_eps = b.take((size_t)B * nz * 4);
+    h->off_eps = b.take((size_t)B * h->ld_eps * 4);
     // cost partial slots: one per output-loss tile (64-wide tiles bound the count) + latent tiles
     int slots = (B + kLatentRows - 1) / kLatentRows;
     for (int m = 0; m < h->M; ++m) slots += ((B + 63) / 64) * ((h->mods[m].n_in + 63) / 64);
@@ -286,7 +290,7 @@ struct Builder {
         w.out0 = p<void>(md.mulv); w.ld0 = 2 * h->nz;
         w.out1 = with_z ? p<void>(md.Z.rm) : nullptr; w.ld1 = md.Z.ld;
         w.out2 = (with_z && train) ? p<void>(md.Z.tr) : nullptr; w.ld2 = md.Z.ldT;
-        w.aux0 = p<void>(h->off_eps);
+        w.aux0 = p<void>(h->off_eps); w.ldx = h->ld_eps;
         return w;
     }
     WorkItem fwd_out(const Mod& md, int m, bool loss) {
@@ -319,7 +323,7 @@ struct Builder {
         const Act& dA = md.dD[0];
         WorkItem w = gemm_item(K_DGRAD_LATENT, B, h->nz, K_of(d.out), p<void>(dA.rm), dA.ld, p<void>(d.W), d.ld);
         w.nz = h->nz;
-        w.aux0 = p<void>(md.mulv); w.aux1 = p<void>(h->off_eps); w.aux2 = p<void>(md.g0);
+        w.aux2 = p<void>(md.g0);
         w.out0 = p<void>(md.dH.rm); w.ld0 = md.dH.ld;
         w.out1 = p<void>(md.dH.tr); w.ld1 = md.dH.ldT;
         return w;
@@ -335,7 +339,14 @@ struct Builder {
         w.kind = K_LATENT; w.M = B; w.nz = h->nz; w.n_mod = h->M;
         const float bg = (float)(h->cfg.batch_global > 0 ? h->cfg.batch_global : h->cfg.batch_size);
         w.inv_bg = 1.0f / bg; w.lambda = h->cfg.assoc_lambda;
-        for (int m = 0; m < h->M; ++m) { w.mulv[m] = p<float>(h->mods[m].mulv); w.g0[m] = p<float>(h->mods[m].g0); w.wts[m] = h->cfg.mod[m].weight; }
+        const void** in_slots[kMaxMod] = {&w.A, &w.B, &w.aux0, &w.aux1};
+        void** out_slots[kMaxMod - 1] = {&w.out0, &w.out1, &w.out2};
+        for (int m = 0; m < h->M; ++m) {
+            *in_slots[m] = p<void>(h->mods[m].mulv);
+            if (m < kMaxMod - 1) *out_slots[m] = p<void>(h->mods[m].g0); else w.aux2 = p<void>(h->mods[m].g0);
+            w.wts[m] = h->cfg.mod[m].weight;
+        }
+        w.eps = p<float>(h->off_eps); w.ldx = h->ld_eps;
         w.partial = p<float>(h->off_partial);
         return w;
     }
@@ -343,6 +354,7 @@ struct Builder {
         WorkItem w;
         std::memset(&w, 0, sizeof(w));
         w.kind = K_COST; w.partial = p<float>(h->off_partial); w.bump_step = bump ? 1 : 0;
+        w.scale = h->cfg.learning_rate; w.lambda = h->cfg.beta1; w.inv_bg = h->cfg.beta2;
         w.out0 = h->grad() + h->P_int;
         return w;
     }
@@ -382,6 +394,10 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         }
     }
     L.blocks = base;
+    if (count > kMaxItemsPerLaunch) throw Err("internal error: too many items in one launch");
+    std::memset(&L.args, 0, sizeof(L.args));
+    L.args.n_items = count;
+    for (int i = 0; i < count; ++i) { L.args.base[i] = items[first + i].tile_base; L.args.items[i] = items[first + i]; }
     if (*next_slot > h->n_partial) throw Err("internal error: cost partial slots overflow");
     return L;
 }
@@ -454,7 +470,6 @@ void build_training_plan(avae_handle* h) {
         h->items.push_back(bd.cost(false));
         h->cost_only = finish_launch(h, h->items, first, 1, "cost_reduce", &slot);
     }
-    if (h->items.size() * sizeof(WorkItem) > h->off_adam - h->off_items) throw Err("internal error: item table overflow");
 
     // ---- Adam tiles
     h->adam_items.clear();
@@ -524,7 +539,7 @@ struct Timed {
     }
 };
 
-void run_launches(avae_handle* h, const std::vector<Launch>& ls, const WorkItem* dev_items, hipStream_t s, int stamp_base = -1) {
+void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, int stamp_base = -1) {
     int k = 0;
     for (const Launch& L : ls) {
         Timed t(h, s, L.name);
@@ -532,7 +547,12 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, const WorkItem*
 #ifdef AVAE_STAMPS
         if (stamp_base >= 0) stamps = h->at<unsigned long long>(h->off_stamps);
 #endif
-        launch_grouped(h->cfg.compute_dtype, L.cfg, dev_items + L.first, L.count, L.blocks, h->state(), s, stamps, stamp_base + k);
+        launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.blocks, h->state(), s, stamps, stamp_base + k);
+        if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to
+            std::fprintf(stderr, "[avae] launch %s cfg=%d items=%d blocks=%d\n", L.name.c_str(), L.cfg, L.count, L.blocks);
+            std::fflush(stderr);
+            HIP_OK(hipStreamSynchronize(s));
+        }
         ++k;
     }
 }
@@ -541,6 +561,8 @@ void run_adam(avae_handle* h, int mode, hipStream_t s) {
     AdamArgs a;
     a.items = h->at<AdamItem>(h->off_adam);
     a.n_items = (int)h->adam_items.size();
+    if (a.n_items > kMaxAdamItems) throw Err("internal error: too many Adam items");
+    for (int i = 0; i < a.n_items; ++i) a.base[i] = h->adam_items[i].tile_base;
     a.mode = mode;
     a.lr = h->cfg.learning_rate; a.beta1 = h->cfg.beta1; a.beta2 = h->cfg.beta2; a.eps = h->cfg.adam_eps;
     a.st = h->state();
@@ -567,7 +589,7 @@ void run_prep_batch(avae_handle* h, const float* const* x, const int32_t* x_ld, 
         base += g.tiles_r * g.tiles_c;
     }
     a.n_seg = h->M; a.total_tiles = base;
-    a.eps_src = eps; a.eps_dst = h->at<float>(h->off_eps); a.eps_rows = rows; a.nz = h->nz;
+    a.eps_src = eps; a.eps_dst = h->at<float>(h->off_eps); a.eps_rows = rows; a.nz = h->nz; a.eps_ld = h->ld_eps;
     a.eps_blocks = (rows * ((h->nz + 3) / 4) + kThreads - 1) / kThreads;
     a.row_offset = h->cfg.row_offset; a.seed = h->cfg.seed; a.st = h->state(); a.stream_salt = salt;
     Timed t(h, s, "prep");
@@ -588,7 +610,7 @@ void run_prep_single(avae_handle* h, const float* src, int src_ld, int rows, int
         a.n_seg = 1; a.total_tiles = g.tiles_r * g.tiles_c;
     }
     if (do_eps) {
-        a.eps_src = eps; a.eps_dst = h->at<float>(h->off_eps); a.eps_rows = rows; a.nz = h->nz;
+        a.eps_src = eps; a.eps_dst = h->at<float>(h->off_eps); a.eps_rows = rows; a.nz = h->nz; a.eps_ld = h->ld_eps;
         a.eps_blocks = (rows * ((h->nz + 3) / 4) + kThreads - 1) / kThreads;
     }
     a.row_offset = h->cfg.row_offset; a.seed = h->cfg.seed; a.st = h->state(); a.stream_salt = salt;
@@ -623,7 +645,6 @@ void init_device(avae_handle* h) {
         for (const Act& a : md.D) fill_ones(h, a, s);
     }
     build_training_plan(h);
-    HIP_OK(hipMemcpyAsync(h->at<void>(h->off_items), h->items.data(), h->items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
     HIP_OK(hipMemcpyAsync(h->at<void>(h->off_adam), h->adam_items.data(), h->adam_items.size() * sizeof(AdamItem), hipMemcpyHostToDevice, s));
     size_t off = h->off_inf;
     h->inf_enc.assign(h->M, avae_handle::Inf());
@@ -634,21 +655,19 @@ void init_device(avae_handle* h) {
     }
     HIP_OK(hipStreamSynchronize(s));
     if (h->cfg.use_graph) {
-        const WorkItem* di = h->at<WorkItem>(h->off_items);
         const bool tsave = h->timing;
         h->timing = false;
-        h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, di, cs); run_launches(h, h->bwd, di, cs); });
+        h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, h->bwd, cs); });
         h->g_adam = capture(h, [&](hipStream_t cs) { run_adam(h, 0, cs); });
-        h->g_full = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, di, cs, 0); run_launches(h, h->bwd, di, cs, (int)h->fwd.size()); run_adam(h, 0, cs); });
-        h->g_eval = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, di, cs); run_launches(h, std::vector<Launch>{h->cost_only}, di, cs); });
+        h->g_full = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs, 0); run_launches(h, h->bwd, cs, (int)h->fwd.size()); run_adam(h, 0, cs); });
+        h->g_eval = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, std::vector<Launch>{h->cost_only}, cs); });
         h->timing = tsave;
     }
 }
 
 void do_backward(avae_handle* h, hipStream_t s) {
-    const WorkItem* di = h->at<WorkItem>(h->off_items);
     if (h->g_bwd && !h->timing) HIP_OK(hipGraphLaunch(h->g_bwd, s));
-    else { run_launches(h, h->fwd, di, s); run_launches(h, h->bwd, di, s); }
+    else { run_launches(h, h->fwd, s); run_launches(h, h->bwd, s); }
 }
 
 void do_apply(avae_handle* h, hipStream_t s) {
@@ -714,6 +733,8 @@ int avae_create(const avae_config* cfg, avae_handle** out) {
         check_config(*cfg);
         h = new avae_handle();
         h->cfg = *cfg;
+        if (const char* e = std::getenv("AVAE_DEBUG_SYNC")) h->debug_sync = e[0] == '1';
+        if (h->debug_sync) h->cfg.use_graph = 0;
         if (h->cfg.beta1 == 0.f && h->cfg.beta2 == 0.f && h->cfg.adam_eps == 0.f) { h->cfg.beta1 = 0.9f; h->cfg.beta2 = 0.999f; h->cfg.adam_eps = 1e-8f; }
         int ndev = 0;
         HIP_OK(hipGetDeviceCount(&ndev));
@@ -851,9 +872,8 @@ int avae_eval_cost(avae_handle* h, const float* const* x_dev, const int32_t* x_l
     return guarded(h, [&] {
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x6576616cull /*eval*/, s);
-        const WorkItem* di = h->at<WorkItem>(h->off_items);
         if (h->g_eval && !h->timing) HIP_OK(hipGraphLaunch(h->g_eval, s));
-        else { run_launches(h, h->fwd, di, s); run_launches(h, std::vector<Launch>{h->cost_only}, di, s); }
+        else { run_launches(h, h->fwd, s); run_launches(h, std::vector<Launch>{h->cost_only}, s); }
         fetch_cost(h, cost_host, false, s);
     });
 }
@@ -861,9 +881,7 @@ int avae_eval_cost(avae_handle* h, const float* const* x_dev, const int32_t* x_l
 static void run_inference(avae_handle* h, int m, bool enc, int rows, hipStream_t s) {
     build_inference(h, m, enc, rows);
     avae_handle::Inf& inf = enc ? h->inf_enc[m] : h->inf_dec[m];
-    // stream-ordered upload: earlier launches that read the old table have completed before it lands
-    HIP_OK(hipMemcpyAsync(h->at<void>(inf.dev_off), inf.items.data(), inf.items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
-    run_launches(h, inf.launches, h->at<WorkItem>(inf.dev_off), s);
+    run_launches(h, inf.launches, s);          // items travel by value in the kernel arguments
 }
 
 int avae_encode(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld, int32_t rows, float* mu_dev, float* logvar_dev, void* stream) {
@@ -1018,7 +1036,14 @@ int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t m
         std::string n(name ? name : "");
         const void* src = nullptr;
         size_t cnt = 0;
-        if (n == "eps") { src = h->at<void>(h->off_eps); cnt = (size_t)h->B * h->nz; }
+        if (n == "eps") {     // internal rows are padded to a multiple of 4 floats: hand back dense [B][n_z]
+            cnt = (size_t)h->B * h->nz;
+            if (cnt > max_floats) throw Err("debug_fetch: destination too small");
+            HIP_OK(hipDeviceSynchronize());
+            HIP_OK(hipMemcpy2D(host_dst, (size_t)h->nz * 4, h->at<void>(h->off_eps), (size_t)h->ld_eps * 4, (size_t)h->nz * 4, h->B, hipMemcpyDeviceToHost));
+            if (n_floats) *n_floats = cnt;
+            return;
+        }
 #ifdef AVAE_STAMPS
         else if (n == "stamps") { src = h->at<void>(h->off_stamps); cnt = (size_t)kStampLaunches * kStampBlocks * kStampWords * 2; }
 #endif
@@ -1026,7 +1051,7 @@ int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t m
             const bool g0 = n[0] == 'g';
             const int m = std::atoi(n.c_str() + (g0 ? 3 : 4));
             if (m < 0 || m >= h->M) throw Err("debug_fetch: modality out of range");
-            src = h->at<void>(g0 ? h->mods[m].g0 : h->mods[m].mulv); cnt = (size_t)h->B * 2 * h->nz;
+            src = h->at<void>(g0 ? h->mods[m].g0 : h->mods[m].mulv); cnt = (size_t)h->B * (g0 ? 3 : 2) * h->nz;
         } else throw Err("debug_fetch: unknown tensor " + n);
         if (cnt > max_floats) throw Err("debug_fetch: destination too small");
         HIP_OK(hipDeviceSynchronize());

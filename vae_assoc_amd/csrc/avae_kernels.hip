@@ -12,8 +12,8 @@
 //
 // Per 256-thread workgroup: a BM x BN output tile (64x64 or 128x128), 4 wave64s in a 2x2
 // arrangement, v_mfma_f32_16x16x32_bf16 (bf16 operands) or v_mfma_f32_16x16x4_f32 (exact fp32),
-// fp32 accumulation in registers, register-staged global->LDS double buffering with 144-byte
-// LDS rows (128 B of K + 16 B pad: conflict-free ds_read_b128 over 16 rows), and an LDS-staged
+// fp32 accumulation in registers, a 4-stage LDS-DMA ring (global_load_lds_dwordx4, XOR-swizzled
+// 128-byte rows: conflict-free ds_read_b128, up to 3 K tiles in flight), and an LDS-staged
 // epilogue that fuses the activation / reparameterisation / loss / gradient maths and writes both
 // the row-major and the transposed result with coalesced vector stores.
 //
@@ -29,7 +29,6 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // native vector: stays in registers (HIP's uint4 struct does not)
 
-constexpr int kLdsRow = kTileBytesK + 16;   // 144 B
 
 // ------------------------------------------------------------------ element helpers
 template <typename CT> __device__ __forceinline__ CT to_ct(float v);
@@ -65,6 +64,31 @@ template <typename OT> __device__ __forceinline__ void store_row(OT* p, const fl
     for (int e = 0; e < 3; ++e) if (e < nvalid) p[e] = to_ct<OT>(v[e]);
 }
 
+// 16-byte vector access of VW consecutive elements (VW = 8 bf16 or 4 fp32 per lane): a 16-B store
+// costs the same issue slot as an 8-B one and the epilogues are store-issue bound.
+template <typename T> struct Vec16 { static constexpr int VW = 16 / (int)sizeof(T); };
+template <typename AT, int VW> __device__ __forceinline__ void load_vec(const AT* p, float* v);
+template <> __device__ __forceinline__ void load_vec<float, 4>(const float* p, float* v) { load4<float>(p, v); }
+template <> __device__ __forceinline__ void load_vec<float, 8>(const float* p, float* v) { load4<float>(p, v); load4<float>(p + 4, v + 4); }
+template <> __device__ __forceinline__ void load_vec<__bf16, 8>(const __bf16* p, float* v) {
+    const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_bits_to_float(t[i] & 0xffffu); v[2 * i + 1] = bf16_bits_to_float(t[i] >> 16); }
+}
+template <> __device__ __forceinline__ void load_vec<__bf16, 4>(const __bf16* p, float* v) { load4<__bf16>(p, v); }
+template <typename OT, int VW> __device__ __forceinline__ void store_vec(OT* p, const float* v, int nvalid);
+template <> __device__ __forceinline__ void store_vec<float, 4>(float* p, const float* v, int nvalid) { store_row<float>(p, v, nvalid); }
+template <> __device__ __forceinline__ void store_vec<__bf16, 8>(__bf16* p, const float* v, int nvalid) {
+    if (nvalid >= 8) {
+        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+        const bf16x8_t t = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+        *reinterpret_cast<bf16x8_t*>(p) = t;
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 7; ++e) if (e < nvalid) p[e] = (__bf16)v[e];
+}
+
 template <typename CT> __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c);
 template <> __device__ __forceinline__ void mma<__bf16>(const u32x4& a, const u32x4& b, f32x4& c) {
     // lane l: A[row l&15][k 8*(l>>4)..+7], B[k 8*(l>>4)..+7][col l&15]; C col l&15, row 4*(l>>4)+reg
@@ -81,52 +105,135 @@ template <> __device__ __forceinline__ void mma<float>(const u32x4& a, const u32
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float sigmoidf_(float a) { return 1.0f / (1.0f + expf(-a)); }
+// Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp): the epilogues are
+// latency-critical and libm's expf/logf/division cost tens of instructions each.
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+__device__ __forceinline__ float flog(float x) { return __logf(x); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float a) { return frcp(1.0f + fexp(-a)); }
+// 2*sinh(h) without cancellation: series below |h| = 0.5, exponentials above
+__device__ __forceinline__ float two_sinh(float h) {
+    const float h2 = h * h;
+    const float ser = 2.0f * h * (1.0f + h2 * (1.0f / 6.0f + h2 * (1.0f / 120.0f + h2 * (1.0f / 5040.0f + h2 * (1.0f / 362880.0f)))));
+    const float e = fexp(h);
+    return fabsf(h) < 0.5f ? ser : e - frcp(e);
+}
 
 __device__ __forceinline__ float act_fwd(int act, float a) {
     switch (act) {
         case AVAE_ACT_RELU: return fmaxf(a, 0.0f);
-        case AVAE_ACT_SOFTPLUS: return fmaxf(a, 0.0f) + log1pf(expf(-fabsf(a)));
+        case AVAE_ACT_SOFTPLUS: return fmaxf(a, 0.0f) + log1pf(fexp(-fabsf(a)));
         case AVAE_ACT_SIGMOID: return sigmoidf_(a);
-        case AVAE_ACT_TANH: return tanhf(a);
+        case AVAE_ACT_TANH: { const float e = fexp(-2.0f * fabsf(a)); const float t = (1.0f - e) * frcp(1.0f + e); return a < 0.0f ? -t : t; }
         default: return a;
     }
 }
+// Compile-time variants: the epilogue loops are instantiated per transfer function and selected by
+// ONE wave-uniform switch outside the loop (a per-element switch kept every branch's libm code
+// in the unrolled loop body and cost ~1.3 us per tile).
+template <int ACT> __device__ __forceinline__ float act_fwd_t(float a) { return act_fwd(ACT, a); }
+__device__ __forceinline__ float act_bwd(int act, float y);
+template <int ACT> __device__ __forceinline__ float act_bwd_t(float y) { return act_bwd(ACT, y); }
+#define AVAE_ACT_DISPATCH(act, CALL)                                   \
+    switch (act) {                                                     \
+        case AVAE_ACT_RELU: { constexpr int ACT = AVAE_ACT_RELU; CALL; } break;          \
+        case AVAE_ACT_SOFTPLUS: { constexpr int ACT = AVAE_ACT_SOFTPLUS; CALL; } break;  \
+        case AVAE_ACT_SIGMOID: { constexpr int ACT = AVAE_ACT_SIGMOID; CALL; } break;    \
+        case AVAE_ACT_TANH: { constexpr int ACT = AVAE_ACT_TANH; CALL; } break;          \
+        default: { constexpr int ACT = AVAE_ACT_IDENTITY; CALL; } break;                 \
+    }
+
 // derivative of the transfer function expressed through its OUTPUT y
 __device__ __forceinline__ float act_bwd(int act, float y) {
     switch (act) {
         case AVAE_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
-        case AVAE_ACT_SOFTPLUS: return 1.0f - expf(-y);
+        case AVAE_ACT_SOFTPLUS: return 1.0f - fexp(-y);
         case AVAE_ACT_SIGMOID: return y * (1.0f - y);
         case AVAE_ACT_TANH: return 1.0f - y * y;
         default: return 1.0f;
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// global store of the wave (its release fence drains vmcnt), which in the epilogues puts a full
+// store round trip (~1 us) in front of each barrier; the data exchanged here lives in LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Sum over the 256 threads of the block, same value returned to every thread, fixed order.
 __device__ __forceinline__ float block_sum(float v, float* red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------ epilogue passes
+// The accumulator tile sits in LDS as fp32 [BM][BN+4].  A pass is written in three phases so that
+// all of a thread's LDS reads and auxiliary global loads are in flight together (no per-quad
+// load->wait->store chains): A) unconditional loads (addresses clamped into the allocation),
+// B) the fused element maths, C) predicated stores.  Partial quads are stored element-wise so the
+// zero padding and the constant-1 column are never touched.
+template <typename OT, typename AT, bool HAS_AUX, bool WRITEBACK, int BM, int BN, typename Op>
+__device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT* aux, int ldx,
+                                          int M, int N, int m0, int n0, Op op) {
+    constexpr int VW = Vec16<OT>::VW;                     // elements per 16-byte store
+    constexpr int LDC = BN + 4, QC = BN / VW, NQ = BM * QC / kThreads;
+    const int tid = threadIdx.x;
+    float c[NQ][VW], a[NQ][VW];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + row * LDC + c0 + 4 * h);
+            c[q][4 * h] = t[0]; c[q][4 * h + 1] = t[1]; c[q][4 * h + 2] = t[2]; c[q][4 * h + 3] = t[3];
+        }
+        if (HAS_AUX) {
+            const int gr = min(m0 + row, M - 1), gc = min(n0 + c0, ldx - VW);   // clamped => that group is never stored
+            load_vec<AT, VW>(aux + (size_t)gr * ldx + gc, a[q]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) a[q][e] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
+        const bool rok = m0 + row < M;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) c[q][e] = op(c[q][e], a[q][e], rok && (n0 + c0 + e < N));
+        if (WRITEBACK) {
+#pragma unroll
+            for (int h = 0; h < VW / 4; ++h)
+                *reinterpret_cast<f32x4*>(Cs + row * LDC + c0 + 4 * h) = f32x4{c[q][4 * h], c[q][4 * h + 1], c[q][4 * h + 2], c[q][4 * h + 3]};
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
+        const int grow = m0 + row, gcol = n0 + c0;
+        if (grow < M && gcol < N) store_vec<OT, VW>(out + (size_t)grow * ld0 + gcol, c[q], N - gcol);
+    }
+}
+
 template <typename OT, int BM, int BN>
 __device__ __forceinline__ void transposed_store(const float* Cs, OT* out, int ld, int M, int N, int m0, int n0) {
-    constexpr int LDC = BN + 4;
-    constexpr int QR = BM / 4;
-    for (int idx = threadIdx.x; idx < BN * QR; idx += kThreads) {
-        const int col = idx / QR, r4 = (idx - col * QR) * 4;
-        const int gcol = n0 + col, grow = m0 + r4;
-        if (gcol < N && grow < M) {
-            float v[4];
+    constexpr int VW = Vec16<OT>::VW;
+    constexpr int LDC = BN + 4, QR = BM / VW, NQ = BN * QR / kThreads;
+    float v[NQ][VW];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = Cs[(r4 + e) * LDC + col];
-            store_row<OT>(out + (size_t)gcol * ld + grow, v, M - grow);
-        }
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = threadIdx.x + q * kThreads, col = idx / QR, r0 = (idx - col * QR) * VW;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) v[q][e] = Cs[(r0 + e) * LDC + col];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = threadIdx.x + q * kThreads, col = idx / QR, r0 = (idx - col * QR) * VW;
+        const int gcol = n0 + col, grow = m0 + r0;
+        if (gcol < N && grow < M) store_vec<OT, VW>(out + (size_t)gcol * ld + grow, v[q], M - grow);
     }
 }
 
@@ -135,21 +242,32 @@ __device__ __forceinline__ void transposed_store(const float* Cs, OT* out, int l
 // their gradients w.r.t. (mu, lv).  The log-determinant terms of the two directed KLs cancel, so
 // per sample and dimension  S = 1/2 [ e^a + e^-a - 2 + D^2 (e^-lvi + e^-lvj) ],  a = lvi-lvj,
 // D = mui-muj;  e^a + e^-a - 2 is evaluated as (2 sinh(a/2))^2 to avoid cancellation.
-__device__ void latent_item(const WorkItem& w, int t, float* red) {
+__device__ __forceinline__ void latent_item(const WorkItem& w, int t, float* red) {
+    const float* mulv[kMaxMod] = {reinterpret_cast<const float*>(w.A), reinterpret_cast<const float*>(w.B),
+                                  reinterpret_cast<const float*>(w.aux0), reinterpret_cast<const float*>(w.aux1)};
+    float* g0[kMaxMod] = {reinterpret_cast<float*>(w.out0), reinterpret_cast<float*>(w.out1),
+                          reinterpret_cast<float*>(w.out2), reinterpret_cast<float*>(const_cast<void*>(w.aux2))};
     const int nz = w.nz, nz2 = 2 * w.nz, M = w.M;
     float csum = 0.0f;
     for (int idx = threadIdx.x; idx < kLatentRows * nz; idx += kThreads) {
         const int row = idx / nz, d = idx - row * nz;
         const int grow = t * kLatentRows + row;
         if (grow >= M) continue;
-        float mu[kMaxMod], lv[kMaxMod], gmu[kMaxMod], glv[kMaxMod];
+        float mu[kMaxMod], lv[kMaxMod], gmu[kMaxMod], glv[kMaxMod], en[kMaxMod];
+        const float eps_v = w.eps[(size_t)grow * w.ldx + d];
 #pragma unroll
         for (int m = 0; m < kMaxMod; ++m) {
-            mu[m] = lv[m] = gmu[m] = glv[m] = 0.0f;
+            mu[m] = lv[m] = gmu[m] = glv[m] = 0.0f; en[m] = 1.0f;
             if (m < w.n_mod) {
-                mu[m] = w.mulv[m][(size_t)grow * nz2 + d];
-                lv[m] = w.mulv[m][(size_t)grow * nz2 + nz + d];
-                const float el = expf(lv[m]);
+                mu[m] = mulv[m][(size_t)grow * nz2 + d];
+                lv[m] = mulv[m][(size_t)grow * nz2 + nz + d];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < kMaxMod; ++m) {
+            if (m < w.n_mod) {
+                const float el = fexp(lv[m]);
+                en[m] = frcp(el);                                   // e^-lv
                 const float s = w.wts[m] * w.inv_bg;
                 csum += s * (-0.5f * (1.0f + lv[m] - mu[m] * mu[m] - el));
                 gmu[m] = s * mu[m];
@@ -162,22 +280,23 @@ __device__ void latent_item(const WorkItem& w, int t, float* red) {
             for (int j = i + 1; j < kMaxMod; ++j) {
                 if (j < w.n_mod) {
                     const float a = lv[i] - lv[j], dl = mu[i] - mu[j];
-                    const float eni = expf(-lv[i]), enj = expf(-lv[j]);
-                    const float sh = 2.0f * sinhf(0.5f * a);
-                    const float dsh = 2.0f * sinhf(a);          // e^a - e^-a
-                    csum += w.lambda * 0.5f * (sh * sh + dl * dl * (eni + enj));
-                    const float gm = w.lambda * dl * (eni + enj);
+                    const float sh = two_sinh(0.5f * a);             // e^(a/2) - e^(-a/2)
+                    const float dsh = two_sinh(a);                   // e^a - e^-a
+                    csum += w.lambda * 0.5f * (sh * sh + dl * dl * (en[i] + en[j]));
+                    const float gm = w.lambda * dl * (en[i] + en[j]);
                     gmu[i] += gm; gmu[j] -= gm;
-                    glv[i] += 0.5f * w.lambda * (dsh - dl * dl * eni);
-                    glv[j] += 0.5f * w.lambda * (-dsh - dl * dl * enj);
+                    glv[i] += 0.5f * w.lambda * (dsh - dl * dl * en[i]);
+                    glv[j] += 0.5f * w.lambda * (-dsh - dl * dl * en[j]);
                 }
             }
         }
 #pragma unroll
         for (int m = 0; m < kMaxMod; ++m) {
             if (m < w.n_mod) {
-                w.g0[m][(size_t)grow * nz2 + d] = gmu[m];
-                w.g0[m][(size_t)grow * nz2 + nz + d] = glv[m];
+                g0[m][(size_t)grow * 3 * nz + d] = gmu[m];
+                g0[m][(size_t)grow * 3 * nz + nz + d] = glv[m];
+                // reparameterisation factor for the backward pass: d z / d lv = 1/2 exp(lv/2) eps
+                g0[m][(size_t)grow * 3 * nz + 2 * nz + d] = 0.5f * eps_v * fexp(0.5f * lv[m]);
             }
         }
     }
@@ -191,21 +310,28 @@ __device__ void cost_item(const WorkItem& w, DevState* st, float* red) {
     const float total = block_sum(s, red);
     if (threadIdx.x == 0) {
         reinterpret_cast<float*>(w.out0)[0] = total;
-        if (w.bump_step) st->step += 1;
+        if (w.bump_step) {
+            const long long tnew = st->step + 1;
+            st->step = tnew;
+            // TF-1 Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), published for the Adam kernel of this step
+            const double b1t = pow((double)w.lambda, (double)tnew), b2t = pow((double)w.inv_bg, (double)tnew);
+            st->lr_t = (float)((double)w.scale * sqrt(1.0 - b2t) / (1.0 - b1t));
+        }
     }
 }
 
 // ------------------------------------------------------------------ the grouped kernel
+constexpr int kRing = 4;                    // LDS ring depth: up to 3 K tiles in flight behind the one being multiplied
 template <int BM, int BN> struct TileSmem {
-    static constexpr int kStage = (BM + BN) * kLdsRow;
-    static constexpr int kStages = 2 * kStage;
-    static constexpr int kC = BM * (BN + 4) * 4;
-    static constexpr int kMain = kStages > kC ? kStages : kC;
+    static constexpr int kStage = (BM + BN) * kTileBytesK;     // linear 128-B rows (LDS-DMA image), XOR-swizzled chunks
+    static constexpr int kStages = kRing * kStage;
+    static constexpr int kC = BM * (BN + 4) * 4;          // fp32 accumulator tile; the latent epilogues use a second one
+    static constexpr int kMain = kStages > 2 * kC ? kStages : 2 * kC;
     static constexpr int kTotal = kMain + 64;
 };
 
 template <typename CT, int BM, int BN>
-__global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict__ items, int n_items, DevState* st,
+__global__ void __launch_bounds__(kThreads) k_grouped(const LaunchArgs args, DevState* st,
                                                       unsigned long long* stamps, int launch_id) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[TileSmem<BM, BN>::kTotal];
     float* red = reinterpret_cast<float*>(smem + TileSmem<BM, BN>::kMain);
@@ -213,10 +339,8 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict
     unsigned long long sv[kStampWords] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define AVAE_STAMP(i) { __builtin_amdgcn_sched_barrier(0); sv[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
 #define AVAE_STAMP_FLUSH() { if (stamps && threadIdx.x == 0 && launch_id < kStampLaunches && blockIdx.x < kStampBlocks) { \
-        sv[6] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
         for (int i_ = 0; i_ < kStampWords; ++i_) stamps[((size_t)launch_id * kStampBlocks + blockIdx.x) * kStampWords + i_] = sv[i_]; } }
     AVAE_STAMP(0)
-    sv[5] = __builtin_amdgcn_s_memtime();
 #else
 #define AVAE_STAMP(i)
 #define AVAE_STAMP_FLUSH()
@@ -224,8 +348,10 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict
 
     const int bid = blockIdx.x;
     int it = 0;
-    while (it + 1 < n_items && bid >= items[it + 1].tile_base) ++it;
-    const WorkItem& w = items[it];
+#pragma unroll
+    for (int i = 1; i < kMaxItemsPerLaunch; ++i)
+        if (i < args.n_items && bid >= args.base[i]) it = i;     // bases ascend; everything is a kernel argument
+    const WorkItem w = args.items[it];                            // one burst of scalar loads from the kernarg segment
     const int t = bid - w.tile_base;
     if (w.kind == K_LATENT) { latent_item(w, t, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
     if (w.kind == K_COST) { cost_item(w, st, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
@@ -252,65 +378,70 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Register-staged double buffering: tile kt+1 is fetched from HBM/L2 into registers while the
-    // MFMAs of tile kt run out of LDS; it is written to the other LDS buffer afterwards.  One
-    // barrier per K tile.  (Plain arrays + fully unrolled loops only: anything fancier lands the
-    // staging registers in scratch.)
-    typedef const __attribute__((address_space(1))) u32x4* gp_t;
-    u32x4 ra[NCA], rb[NCB];
-    const int srow = tid >> 3, sch = tid & 7;       // this thread stages rows srow + 32*c, 16-B chunk sch
-    const unsigned char* Ath = Ag + srow * lda_b + sch * 16;
-    const unsigned char* Bth = Bg + srow * ldb_b + sch * 16;
-    const int soff = srow * kLdsRow + sch * 16;
+    // K loop: LDS-DMA ring.  Each wave-instruction global_load_lds_dwordx4 moves 8 rows x 128 B
+    // (1 KiB) straight from HBM/L2 into LDS (no staging registers); kRing stages, up to kRing-1 K
+    // tiles in flight, one barrier per tile.  The LDS image is linear (a DMA cannot scatter), so the
+    // bank-conflict swizzle is applied on the per-lane SOURCE address and again on the ds_read:
+    // 16-B chunk c of tile row r lives at chunk c ^ ((r >> 1) & 7)  (conflict-free ds_read_b128).
+    // Ordering: a tile may be read after (this wave's counted vmcnt) + (a barrier every wave passed);
+    // a stage is re-filled only after the barrier that follows its last read.
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    constexpr int R8 = (BM + BN) / 8;          // wave-instructions per tile
+    constexpr int NCH = R8 / 4;                // per wave
     const int fr = lane & 15, fq = lane >> 4;
-    const int aoff = (wr * WM + fr) * kLdsRow + fq * 16;
-    const int boff = BM * kLdsRow + (wc * WN + fr) * kLdsRow + fq * 16;
+    const unsigned char* src[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int r = (c * 4 + wave) * 8 + (lane >> 3);                 // row of the (A rows, then B rows) tile image
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);                     // logical chunk this lane fetches
+        src[c] = (r < BM ? Ag + (size_t)r * lda_b : Bg + (size_t)(r - BM) * ldb_b) + lc * 16;
+    }
+    const int sw0 = (fq ^ (fr >> 1)) * 16;                              // swizzled chunk of K-slab 0; slab 1 = ^64
+    const int aoff = (wr * WM + fr) * kTileBytesK;
+    const int boff = (BM + wc * WN + fr) * kTileBytesK;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
-#define AVAE_GLOAD(kt)                                                                                 \
+#define AVAE_DMA(kt, buf)                                                                              \
     {                                                                                                  \
-        _Pragma("unroll") for (int c = 0; c < NCA; ++c)                                                \
-            ra[c] = *(gp_t)(Ath + (size_t)(32 * c) * lda_b + (size_t)(kt) * kTileBytesK);              \
-        _Pragma("unroll") for (int c = 0; c < NCB; ++c)                                                \
-            rb[c] = *(gp_t)(Bth + (size_t)(32 * c) * ldb_b + (size_t)(kt) * kTileBytesK);              \
+        _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                                \
+            __builtin_amdgcn_global_load_lds((gp_t)(src[c] + (size_t)(kt) * kTileBytesK),              \
+                (lp_t)(smem + (buf) * TileSmem<BM, BN>::kStage + (c * 4 + wave_u) * 1024), 16, 0, 0);  \
     }
-#define AVAE_SWRITE(buf)                                                                               \
-    {                                                                                                  \
-        unsigned char* Sb = smem + (buf) * TileSmem<BM, BN>::kStage + soff;                            \
-        _Pragma("unroll") for (int c = 0; c < NCA; ++c)                                                \
-            *reinterpret_cast<u32x4*>(Sb + 32 * c * kLdsRow) = ra[c];                                  \
-        _Pragma("unroll") for (int c = 0; c < NCB; ++c)                                                \
-            *reinterpret_cast<u32x4*>(Sb + (BM + 32 * c) * kLdsRow) = rb[c];                           \
-    }
+#define AVAE_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define AVAE_COMPUTE(buf)                                                                              \
     {                                                                                                  \
         const unsigned char* Sb = smem + (buf) * TileSmem<BM, BN>::kStage;                             \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                \
             u32x4 a[MI], b[NI];                                                                        \
             _Pragma("unroll") for (int i = 0; i < MI; ++i)                                             \
-                a[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kLdsRow + s * 64);         \
+                a[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + (sw0 ^ (s * 64)));  \
             _Pragma("unroll") for (int j = 0; j < NI; ++j)                                             \
-                b[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kLdsRow + s * 64);         \
+                b[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + (sw0 ^ (s * 64)));  \
             _Pragma("unroll") for (int i = 0; i < MI; ++i)                                             \
                 _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a[i], b[j], acc[i][j]);         \
         }                                                                                              \
     }
 
     AVAE_STAMP(1)
-    AVAE_GLOAD(0)
-    AVAE_SWRITE(0)
-    __syncthreads();
-    AVAE_STAMP(2)
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        AVAE_GLOAD(kt + 1)
-        AVAE_COMPUTE(kt & 1)
-        AVAE_SWRITE((kt + 1) & 1)
-        __syncthreads();
+    {
+        const int npro = nk < kRing - 1 ? nk : kRing - 1;
+        for (int p = 0; p < npro; ++p) AVAE_DMA(p, p)
     }
-    AVAE_COMPUTE((nk - 1) & 1)
-    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;           // tiles issued behind kt: min(rem, kRing - 2)
+        if (rem >= 2) AVAE_WAIT(2 * NCH);
+        else if (rem == 1) AVAE_WAIT(NCH);
+        else AVAE_WAIT(0);
+        asm volatile("s_barrier" ::: "memory");
+        if (kt == 0) { AVAE_STAMP(2) }
+        if (kt + kRing - 1 < nk) AVAE_DMA(kt + kRing - 1, (kt + kRing - 1) & (kRing - 1))
+        AVAE_COMPUTE(kt & (kRing - 1))
+    }
+    lds_barrier();
     AVAE_STAMP(3)
-#undef AVAE_GLOAD
-#undef AVAE_SWRITE
+#undef AVAE_DMA
+#undef AVAE_WAIT
 #undef AVAE_COMPUTE
 
     // ---- epilogue: accumulators -> LDS tile (fp32), then kind-specific fused passes
@@ -325,51 +456,48 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict
                 for (int r = 0; r < 4; ++r)
                     Cs[(wr * WM + i * 16 + fq * 4 + r) * LDC + wc * WN + j * 16 + fr] = acc[i][j][r];
     }
-    __syncthreads();
+    lds_barrier();
+    AVAE_STAMP(5)
 
     const int M = w.M, N = w.N;
     constexpr int QC = BN / 4;
     switch (w.kind) {
     case K_FWD_HIDDEN: {
         CT* Y = reinterpret_cast<CT*>(w.out0);
-        for (int idx = tid; idx < BM * QC; idx += kThreads) {
-            const int row = idx / QC, c4 = (idx - row * QC) * 4;
-            const int grow = m0 + row, gcol = n0 + c4;
-            if (grow < M && gcol < N) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = act_fwd(w.act, Cs[row * LDC + c4 + e]); Cs[row * LDC + c4 + e] = v[e]; }
-                store_row<CT>(Y + (size_t)grow * w.ld0 + gcol, v, N - gcol);
-            }
-        }
+        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, false, true, BM, BN>(Cs, Y, w.ld0, (const CT*)nullptr, 4, M, N, m0, n0,
+            [](float c, float, bool) { return act_fwd_t<ACT>(c); })))
+        AVAE_STAMP(6)
         if (w.out1) {
-            __syncthreads();
+            lds_barrier();
             transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
         }
     } break;
     case K_FWD_HEAD: {
         // columns [0,nz) = mu, [nz,2nz) = log sigma^2 (vae_assoc.py:217-221); z = mu + sqrt(exp(lv))*eps (:102-103)
         const int nz = w.nz;
-        float* mulv = reinterpret_cast<float*>(w.out0);
-        CT* Z = reinterpret_cast<CT*>(w.out1);
+        float* Zs = Cs + BM * LDC;                         // second fp32 tile: z
         const float* eps = reinterpret_cast<const float*>(w.aux0);
-        for (int idx = tid; idx < BM * nz; idx += kThreads) {
-            const int row = idx / nz, d = idx - row * nz;
-            const int grow = m0 + row;
-            if (grow < M) {
-                const float mu = Cs[row * LDC + d], lv = Cs[row * LDC + nz + d];
-                mulv[(size_t)grow * w.ld0 + d] = mu;
-                mulv[(size_t)grow * w.ld0 + nz + d] = lv;
-                if (Z) {
-                    const float z = mu + expf(0.5f * lv) * eps[(size_t)grow * nz + d];
-                    Z[(size_t)grow * w.ld1 + d] = to_ct<CT>(z);
-                    Cs[row * LDC + d] = z;
-                }
+        if (w.out1) {
+            constexpr int NI = BM * (BN / 2) / kThreads;   // nz <= BN/2
+            float ev[NI];
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const int idx = tid + q * kThreads, row = idx / nz, d = idx - row * nz;
+                ev[q] = (idx < BM * nz) ? eps[(size_t)min(m0 + row, M - 1) * w.ldx + d] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const int idx = tid + q * kThreads, row = idx / nz, d = idx - row * nz;
+                if (idx < BM * nz) Zs[row * LDC + d] = Cs[row * LDC + d] + fexp(0.5f * Cs[row * LDC + nz + d]) * ev[q];
             }
         }
-        if (Z && w.out2) {
-            __syncthreads();
-            transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out2), w.ld2, M, nz, m0, 0);
+        tile_pass<float, float, false, false, BM, BN>(Cs, reinterpret_cast<float*>(w.out0), w.ld0, (const float*)nullptr, 4,
+                                                      M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
+        if (w.out1) {
+            lds_barrier();
+            tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out1), w.ld1, (const CT*)nullptr, 8,
+                                                    M, nz, m0, 0, [](float c, float, bool) { return c; });
+            if (w.out2) transposed_store<CT, BM, BN>(Zs, reinterpret_cast<CT*>(w.out2), w.ld2, M, nz, m0, 0);
         }
     } break;
     case K_FWD_OUT_LOSS: {
@@ -377,112 +505,87 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict
         // Gaussian : sum (x-a)^2 / 2 over the WHOLE batch, not averaged          (:327-328,:340)
         CT* dA = reinterpret_cast<CT*>(w.out0);
         const float* X = reinterpret_cast<const float*>(w.aux0);
+        const float sc = w.scale;
         float csum = 0.0f;
-        for (int idx = tid; idx < BM * QC; idx += kThreads) {
-            const int row = idx / QC, c4 = (idx - row * QC) * 4;
-            const int grow = m0 + row, gcol = n0 + c4;
-            if (grow < M && gcol < N) {
-                float v[4], x[4];
-                load4<float>(X + (size_t)grow * w.ldx + gcol, x);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = Cs[row * LDC + c4 + e];
-                    float da = 0.0f;
-                    if (gcol + e < N) {
-                        if (w.binary) {
-                            const float p = sigmoidf_(a);
-                            const float lp = 1e-3f + p, lq = 1e-3f + 1.0f - p;
-                            csum += -w.scale * (x[e] * logf(lp) + (1.0f - x[e]) * logf(lq));
-                            da = w.scale * p * (1.0f - p) * (-x[e] / lp + (1.0f - x[e]) / lq);
-                        } else {
-                            const float df = a - x[e];
-                            csum += w.scale * 0.5f * df * df;
-                            da = w.scale * df;
-                        }
-                    }
-                    v[e] = da;
-                    Cs[row * LDC + c4 + e] = da;
-                }
-                store_row<CT>(dA + (size_t)grow * w.ld0 + gcol, v, N - gcol);
-            }
+        if (w.binary) {
+            tile_pass<CT, float, true, true, BM, BN>(Cs, dA, w.ld0, X, w.ldx, M, N, m0, n0,
+                [&csum, sc](float a, float x, bool ok) {
+                    const float en = fexp(-a), p = frcp(1.0f + en);
+                    const float lp = 1e-3f + p, lq = 1e-3f + 1.0f - p;
+                    const float loss = -(x * flog(lp) + (1.0f - x) * flog(lq));
+                    const float da = sc * p * (1.0f - p) * ((1.0f - x) * lp - x * lq) * frcp(lp * lq);
+                    csum += ok ? sc * loss : 0.0f;
+                    return ok ? da : 0.0f;
+                });
+        } else {
+            tile_pass<CT, float, true, true, BM, BN>(Cs, dA, w.ld0, X, w.ldx, M, N, m0, n0,
+                [&csum, sc](float a, float x, bool ok) {
+                    const float df = a - x;
+                    csum += ok ? sc * 0.5f * df * df : 0.0f;
+                    return ok ? sc * df : 0.0f;
+                });
         }
         const float total = block_sum(csum, red);
         if (tid == 0) w.partial[w.slot_base + t] = total;
         if (w.out1) {
-            __syncthreads();
+            lds_barrier();
             transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
         }
     } break;
     case K_FWD_OUT_STORE: {
         float* O = reinterpret_cast<float*>(w.out0);
-        for (int idx = tid; idx < BM * QC; idx += kThreads) {
-            const int row = idx / QC, c4 = (idx - row * QC) * 4;
-            const int grow = m0 + row, gcol = n0 + c4;
-            if (grow < M && gcol < N) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float a = Cs[row * LDC + c4 + e]; v[e] = w.binary ? sigmoidf_(a) : a; }
-                store_row<float>(O + (size_t)grow * w.ld0 + gcol, v, N - gcol);
-            }
-        }
+        if (w.binary)
+            tile_pass<float, float, false, false, BM, BN>(Cs, O, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
+                [](float a, float, bool) { return sigmoidf_(a); });
+        else
+            tile_pass<float, float, false, false, BM, BN>(Cs, O, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
+                [](float a, float, bool) { return a; });
     } break;
     case K_DGRAD_HIDDEN: {
         CT* dX = reinterpret_cast<CT*>(w.out0);
         const CT* Yp = reinterpret_cast<const CT*>(w.aux0);
-        for (int idx = tid; idx < BM * QC; idx += kThreads) {
-            const int row = idx / QC, c4 = (idx - row * QC) * 4;
-            const int grow = m0 + row, gcol = n0 + c4;
-            if (grow < M && gcol < N) {
-                float v[4], y[4];
-                load4<CT>(Yp + (size_t)grow * w.ldx + gcol, y);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = Cs[row * LDC + c4 + e] * act_bwd(w.act, y[e]); Cs[row * LDC + c4 + e] = v[e]; }
-                store_row<CT>(dX + (size_t)grow * w.ld0 + gcol, v, N - gcol);
-            }
-        }
+        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, true, true, BM, BN>(Cs, dX, w.ld0, Yp, w.ldx, M, N, m0, n0,
+            [](float c, float y, bool) { return c * act_bwd_t<ACT>(y); })))
         if (w.out1) {
-            __syncthreads();
+            lds_barrier();
             transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
         }
     } break;
     case K_DGRAD_LATENT: {
-        // dz -> (dmu, dlv): dmu = dz + g0mu; dlv = dz * 1/2 exp(lv/2) eps + g0lv   (reparam :102-103)
+        // dz -> (dmu, dlv): dmu = dz + g0mu; dlv = dz * F + g0lv with F = 1/2 exp(lv/2) eps   (reparam :102-103);
+        // g0 = [g0mu | g0lv | F] per row comes from the K_LATENT item of the forward pass
         const int nz = w.nz;
-        CT* dH = reinterpret_cast<CT*>(w.out0);
-        const float* mulv = reinterpret_cast<const float*>(w.aux0);
-        const float* eps = reinterpret_cast<const float*>(w.aux1);
+        float* Zs = Cs + BM * LDC;
         const float* g0 = reinterpret_cast<const float*>(w.aux2);
-        for (int idx = tid; idx < BM * nz; idx += kThreads) {
-            const int row = idx / nz, d = idx - row * nz;
-            const int grow = m0 + row;
-            if (grow < M) {
-                const float dz = Cs[row * LDC + d];
-                const float lv = mulv[(size_t)grow * 2 * nz + nz + d];
-                const float dmu = dz + g0[(size_t)grow * 2 * nz + d];
-                const float dlv = dz * 0.5f * expf(0.5f * lv) * eps[(size_t)grow * nz + d] + g0[(size_t)grow * 2 * nz + nz + d];
-                dH[(size_t)grow * w.ld0 + d] = to_ct<CT>(dmu);
-                dH[(size_t)grow * w.ld0 + nz + d] = to_ct<CT>(dlv);
-                Cs[row * LDC + d] = dmu;
-                Cs[row * LDC + nz + d] = dlv;
+        {
+            constexpr int NI = BM * (BN / 2) / kThreads;
+            float gm[NI], gl[NI], gf[NI];
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const int idx = tid + q * kThreads, row = idx / nz, d = idx - row * nz;
+                const size_t o = (size_t)min(m0 + row, M - 1) * 3 * nz + d;
+                const bool ok = idx < BM * nz;
+                gm[q] = ok ? g0[o] : 0.0f; gl[q] = ok ? g0[o + nz] : 0.0f; gf[q] = ok ? g0[o + 2 * nz] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const int idx = tid + q * kThreads, row = idx / nz, d = idx - row * nz;
+                if (idx < BM * nz) {
+                    const float dz = Cs[row * LDC + d];
+                    Zs[row * LDC + d] = dz + gm[q];
+                    Zs[row * LDC + nz + d] = dz * gf[q] + gl[q];
+                }
             }
         }
-        if (w.out1) {
-            __syncthreads();
-            transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, 2 * nz, m0, 0);
-        }
+        lds_barrier();
+        tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out0), w.ld0, (const CT*)nullptr, 8,
+                                                M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
+        if (w.out1) transposed_store<CT, BM, BN>(Zs, reinterpret_cast<CT*>(w.out1), w.ld1, M, 2 * nz, m0, 0);
     } break;
     case K_WGRAD: {
         float* G = reinterpret_cast<float*>(w.out0);
-        for (int idx = tid; idx < BM * QC; idx += kThreads) {
-            const int row = idx / QC, c4 = (idx - row * QC) * 4;
-            const int grow = m0 + row, gcol = n0 + c4;
-            if (grow < M && gcol < N) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = Cs[row * LDC + c4 + e];
-                store_row<float>(G + (size_t)grow * w.ld0 + gcol, v, N - gcol);
-            }
-        }
+        tile_pass<float, float, false, false, BM, BN>(Cs, G, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
+            [](float c, float, bool) { return c; });
     } break;
     default: break;
     }
@@ -490,15 +593,15 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const WorkItem* __restrict
     AVAE_STAMP_FLUSH()
 }
 
-void launch_grouped(int compute_dtype, int tile_cfg, const WorkItem* items, int n_items, int n_blocks,
+void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int n_blocks,
                     DevState* st, hipStream_t s, unsigned long long* stamps, int launch_id) {
     dim3 grid(n_blocks), block(kThreads);
     if (compute_dtype == AVAE_BF16) {
-        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<__bf16, 64, 64>), grid, block, 0, s, items, n_items, st, stamps, launch_id);
-        else hipLaunchKernelGGL((k_grouped<__bf16, 128, 128>), grid, block, 0, s, items, n_items, st, stamps, launch_id);
+        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<__bf16, 64, 64>), grid, block, 0, s, args, st, stamps, launch_id);
+        else hipLaunchKernelGGL((k_grouped<__bf16, 128, 128>), grid, block, 0, s, args, st, stamps, launch_id);
     } else {
-        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<float, 64, 64>), grid, block, 0, s, items, n_items, st, stamps, launch_id);
-        else hipLaunchKernelGGL((k_grouped<float, 128, 128>), grid, block, 0, s, items, n_items, st, stamps, launch_id);
+        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<float, 64, 64>), grid, block, 0, s, args, st, stamps, launch_id);
+        else hipLaunchKernelGGL((k_grouped<float, 128, 128>), grid, block, 0, s, args, st, stamps, launch_id);
     }
 }
 
@@ -511,27 +614,21 @@ void launch_grouped(int compute_dtype, int tile_cfg, const WorkItem* items, int 
 template <typename CT>
 __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
     __shared__ float T[64][65];
-    __shared__ float s_lr;
     const int bid = blockIdx.x, tid = threadIdx.x;
     int it = 0;
-    while (it + 1 < a.n_items && bid >= a.items[it + 1].tile_base) ++it;
-    const AdamItem& w = a.items[it];
+    for (int i = 1; i < a.n_items; ++i)
+        if (bid >= a.base[i]) it = i;                       // kernel-argument table, ascending
+    const AdamItem w = a.items[it];
     const int t = bid - w.tile_base;
     const int tr = t / w.tiles_c, tc = t - tr * w.tiles_c;
     const int r0 = tr * 64, c0 = tc * 64;
 
-    if (a.mode == 0 && tid == 0) {
-        const double ts = (double)a.st->step;     // already counts this step (bumped by K_COST)
-        const double b1t = pow((double)a.beta1, ts), b2t = pow((double)a.beta2, ts);
-        s_lr = (float)((double)a.lr * sqrt(1.0 - b2t) / (1.0 - b1t));
-        if (bid == 0) {
-            const float c = *a.cost_src;
-            a.st->last_cost = c;
-            a.st->cost_hist[(a.st->step - 1) % kCostHist] = c;
-        }
+    if (a.mode == 0 && tid == 0 && bid == 0) {              // step already counts this update (bumped by K_COST)
+        const float c = *a.cost_src;
+        a.st->last_cost = c;
+        a.st->cost_hist[(a.st->step - 1) % kCostHist] = c;
     }
-    __syncthreads();
-    const float lr_t = a.mode == 0 ? s_lr : 0.0f;
+    const float lr_t = a.mode == 0 ? a.st->lr_t : 0.0f;
     const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
 
     const int c4 = (tid & 15) * 4;
@@ -564,7 +661,7 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) T[r][c4 + e] = th[e];
     }
-    __syncthreads();
+    lds_barrier();
     const int r4 = (tid & 15) * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -615,7 +712,7 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
         float n[4];
         if (a.eps_src) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) n[e] = (4 * d4 + e < a.nz) ? a.eps_src[(size_t)row * a.nz + 4 * d4 + e] : 0.0f;
+            for (int e = 0; e < 4; ++e) n[e] = (4 * d4 + e < a.nz) ? a.eps_src[(size_t)row * a.nz + 4 * d4 + e] : 0.0f;   // caller's eps is dense [rows][n_z]
         } else {
             const unsigned long long step = (unsigned long long)a.st->step;
             unsigned r[4];
@@ -625,14 +722,14 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
             // Box-Muller on (0,1) uniforms built from the top 24 bits
             const float u0 = ((r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
             const float u2 = ((r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((r[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-            const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
-            const float tw = 6.28318530717958647692f;
-            n[0] = ra * cosf(tw * u1); n[1] = ra * sinf(tw * u1);
-            n[2] = rb * cosf(tw * u3); n[3] = rb * sinf(tw * u3);
+            const float ra = sqrtf(-2.0f * flog(u0)), rb = sqrtf(-2.0f * flog(u2));
+            // v_sin_f32 / v_cos_f32 take their argument in revolutions: sin(2*pi*u) directly
+            n[0] = ra * __builtin_amdgcn_cosf(u1); n[1] = ra * __builtin_amdgcn_sinf(u1);
+            n[2] = rb * __builtin_amdgcn_cosf(u3); n[3] = rb * __builtin_amdgcn_sinf(u3);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (4 * d4 + e < a.nz) a.eps_dst[(size_t)row * a.nz + 4 * d4 + e] = n[e];
+            if (4 * d4 + e < a.nz) a.eps_dst[(size_t)row * a.eps_ld + 4 * d4 + e] = n[e];
         return;
     }
     int it = 0;
@@ -659,7 +756,7 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
         for (int e = 0; e < 4; ++e) T[r][c4 + e] = v[e];
     }
     if (!w.dstct) return;
-    __syncthreads();
+    lds_barrier();
     const int r4 = (tid & 15) * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
