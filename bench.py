@@ -66,15 +66,17 @@ def dense_layers(na):
     return enc, head, dec, (prev, n_in)
 
 
-def launch_work(archs, B, es):
+def launch_work(archs, B, es, fused_adam=True):
     """Algorithmic HBM bytes and FLOPs of every launch of one step (SURVEY.md 8d accounting:
-    operands read once, results written once, compute-dtype activations, fp32 grads/Adam)."""
+    operands read once, results written once, compute-dtype activations, fp32 Adam state).
+    Launch names mirror avae_host.hip::build_training_plan."""
     out = {}
 
     def add(name, by, fl):
         b0, f0 = out.get(name, (0, 0))
         out[name] = (b0 + by, f0 + fl)
     P = 0
+    wg = []                                   # (bytes, flops, params) per weight-gradient item, in launch order
     for na in archs:
         enc, head, dec, outl = dense_layers(na)
         L = len(enc)
@@ -85,27 +87,39 @@ def launch_work(archs, B, es):
         add("fwd_head", (B * i + (i + 1) * o) * es + B * o * 4 + B * nz * (4 + es), 2 * B * (i + 1) * o)
         for k, (i, o) in enumerate(dec):
             add("fwd_dec%d" % (k + 1), (B * i + (i + 1) * o + B * o) * es, 2 * B * (i + 1) * o)
-        add("fwd_dec1", 2 * B * 2 * nz * 4, 0)                                   # latent item: mulv in, g0 out
+        add("fwd_dec1", B * (2 + 3) * nz * 4, 0)                                 # latent item: mulv in, static grads out
         i, o = outl
         add("fwd_out_loss", (B * i + (i + 1) * o + B * o) * es + B * o * 4, 2 * B * (i + 1) * o)
 
-        def bwd(name, i, o, dgrad=True):
-            by = (B * i + B * o) * es + (i + 1) * o * 4                          # wgrad: X, dA in; G out
-            fl = 2 * B * (i + 1) * o
-            if dgrad:
-                by += (B * o + i * o + 2 * B * i) * es
-                fl += 2 * B * i * o
-            add(name, by, fl)
-        bwd("bwd_out", *outl)
+        def dgrad(name, i, o):                                                   # dA, W, Y_prev in; dA_prev out
+            add(name, (B * o + i * o + 2 * B * i) * es, 2 * B * i * o)
+
+        def wgrad(i, o):                                                         # X, dA in (+ optimiser traffic below)
+            wg.append(((B * i + B * o) * es, 2 * B * (i + 1) * o, (i + 1) * o))
+        dgrad("bwd_out", *outl)
         for k in range(L - 1, 0, -1):
-            bwd("bwd_dec%d" % (k + 1), *dec[k])
-        bwd("bwd_dec1_latent", *dec[0])
-        bwd("bwd_head", *head)
+            dgrad("bwd_dec%d" % (k + 1), *dec[k])
+        dgrad("bwd_dec1_latent", *dec[0])
+        dgrad("bwd_head", *head)
         for k in range(L - 1, 0, -1):
-            bwd("bwd_enc%d" % (k + 1), *enc[k])
-        bwd("bwd_enc1", *enc[0], dgrad=False)
+            dgrad("bwd_enc%d" % (k + 1), *enc[k])
+        wgrad(*outl)
+        for k in range(L - 1, 0, -1):
+            wgrad(*dec[k])
+        wgrad(*dec[0])
+        wgrad(*head)
+        for k in range(L - 1, 0, -1):
+            wgrad(*enc[k])
+        wgrad(*enc[0])
         add("prep", B * n_in * (4 + 4 + es), 0)
         P += sum((i + 1) * o for i, o in enc + dec + [head, outl])
+    chunk = 12                                                                   # kMaxItemsPerLaunch
+    for c0 in range(0, len(wg), chunk):
+        suffix = str(c0 // chunk + 1) if len(wg) > chunk else ""
+        for by, fl, p in wg[c0:c0 + chunk]:
+            # fused: theta/m/v read+write (6 x 4 B) + one compute-dtype shadow; the gradient never has to reach HBM
+            add("wgrad_adam" + suffix, by + p * (6 * 4 + es), fl)
+            add("wgrad" + suffix, by + p * 4, fl)                                # plain: fp32 gradient out
     add("adam", 7 * P * 4 + P * es, 0)
     return out, P
 
@@ -227,8 +241,9 @@ def main():
                 roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
             roof.update({"traffic": None, "kernel": dom, "avg_us": round(kern[dom][1] * 1e3, 2),
                          "algorithmic_bytes": by, "algorithmic_flop": fl})
-        step_bytes = sum(v[0] for v in work.values())
-        step_flop = sum(v[1] for v in work.values())
+        in_step = [n for n in work if n in kern or n == "prep"]
+        step_bytes = sum(work[n][0] for n in in_step)
+        step_flop = sum(work[n][1] for n in in_step)
         out = {
             "metric": "paired-samples/sec (img+jnt assoc-VAE train step)",
             "value": round(B * world * args.steps / dt, 1),

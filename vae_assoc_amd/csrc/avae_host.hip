@@ -94,7 +94,8 @@ struct avae_handle {
     hipStream_t cap_stream = nullptr;
 
     std::vector<WorkItem> items;            // training + eval tables (host mirror)
-    std::vector<Launch> fwd, bwd;           // training launches
+    std::vector<Launch> fwd, bwd;           // training launches: forward, dgrad chain
+    std::vector<Launch> wg_plain, wg_adam;  // all weight gradients: plain (-> all-reduce -> k_adam) or with Adam fused
     Launch cost_only;                       // eval: K_COST alone, no step bump
     std::vector<AdamItem> adam_items;
     int adam_blocks = 0;
@@ -328,9 +329,17 @@ struct Builder {
         w.out1 = p<void>(md.dH.tr); w.ld1 = md.dH.ldT;
         return w;
     }
-    WorkItem wgrad(const Act& x, const Dense& d, const Act& dA) {
-        WorkItem w = gemm_item(K_WGRAD, d.in + 1, d.out, K_of(B), p<void>(x.tr), x.ldT, p<void>(dA.tr), dA.ldT);
+    WorkItem wgrad(const Act& x, const Dense& d, const Act& dA, bool adam = false) {
+        WorkItem w = gemm_item(adam ? K_WGRAD_ADAM : K_WGRAD, d.in + 1, d.out, K_of(B), p<void>(x.tr), x.ldT, p<void>(dA.tr), dA.ldT);
         w.out0 = h->grad() + d.master; w.ld0 = d.ld;
+        if (adam) {
+            w.out1 = p<void>(d.W); w.ld1 = d.ld;
+            w.out2 = p<void>(d.Wt); w.ld2 = d.ldt;
+            w.aux0 = p<float>(h->off_theta) + d.master;
+            w.aux1 = p<float>(h->off_m) + d.master;
+            w.aux2 = p<float>(h->off_v) + d.master;
+            w.scale = h->cfg.beta1; w.lambda = h->cfg.beta2; w.inv_bg = h->cfg.adam_eps;
+        }
         return w;
     }
     WorkItem latent() {
@@ -360,6 +369,8 @@ struct Builder {
     }
 };
 
+inline bool is_gemm(int kind) { return kind <= K_WGRAD || kind == K_WGRAD_ADAM; }
+
 // Fixes the tile configuration of one launch and lays its items' tiles out back to back.
 Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, int count, const std::string& name, int* next_slot) {
     Launch L;
@@ -369,15 +380,16 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
     for (int i = first; i < first + count; ++i) {
         const WorkItem& w = items[i];
         if ((w.kind == K_FWD_HEAD || w.kind == K_DGRAD_LATENT) && 2 * w.nz > 64) need128 = true;
-        if (w.kind <= K_WGRAD) tiles128 += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
+        if (is_gemm(w.kind)) tiles128 += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
     }
     L.cfg = (need128 || tiles128 >= 192) ? 1 : 0;
     const int T = L.cfg ? 128 : 64;
     int base = 0;
     for (int i = first; i < first + count; ++i) {
         WorkItem& w = items[i];
+        base = (base + 7) & ~7;          // item bases are multiples of 8 (the kernel's XCD-aware tile order needs it)
         w.tile_base = base;
-        if (w.kind <= K_WGRAD) {
+        if (is_gemm(w.kind)) {
             w.tiles_m = (w.M + T - 1) / T;
             w.tiles_n = (w.N + T - 1) / T;
             if ((w.kind == K_FWD_HEAD || w.kind == K_DGRAD_LATENT) && w.tiles_n != 1) throw Err("internal error: head tile");
@@ -403,7 +415,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
 }
 
 void build_training_plan(avae_handle* h) {
-    h->items.clear(); h->fwd.clear(); h->bwd.clear();
+    h->items.clear(); h->fwd.clear(); h->bwd.clear(); h->wg_plain.clear(); h->wg_adam.clear();
     Builder bd(h, h->items, h->B, true);
     int slot = 0;
     int Lmax = 0;
@@ -427,43 +439,43 @@ void build_training_plan(avae_handle* h) {
             if (k == 0) h->items.push_back(bd.latent());     // needs every modality's (mu, lv): ready after fwd_head
         });
     group("fwd_out_loss", h->fwd, [&] { for (int m = 0; m < h->M; ++m) h->items.push_back(bd.fwd_out(h->mods[m], m, true)); });
-    // ---- backward: each launch = the dgrad through layer l and the wgrad of layer l (both need only dA_l)
-    group("bwd_out", h->bwd, [&] {
-        for (Mod& md : h->mods) {
-            h->items.push_back(bd.dgrad_hidden(md.dO, md.outl, md.D.back(), md.dD.back()));
-            h->items.push_back(bd.wgrad(md.D.back(), md.outl, md.dO));
-        }
-    });
+    // ---- backward: the dgrad chain (one launch per layer, both modalities), then EVERY weight
+    // gradient in one final wave of launches: they depend only on stored activations / activation
+    // gradients, and being last lets the single-replica path fuse Adam + shadow refresh into their
+    // epilogues (no launch reads a weight shadow afterwards, so updating in place is hazard-free).
+    group("bwd_out", h->bwd, [&] { for (Mod& md : h->mods) h->items.push_back(bd.dgrad_hidden(md.dO, md.outl, md.D.back(), md.dD.back())); });
     for (int k = Lmax - 1; k >= 1; --k)
         group("bwd_dec" + std::to_string(k + 1), h->bwd, [&] {
-            for (Mod& md : h->mods) if (k < md.L) {
-                h->items.push_back(bd.dgrad_hidden(md.dD[k], md.dec[k], md.D[k - 1], md.dD[k - 1]));
-                h->items.push_back(bd.wgrad(md.D[k - 1], md.dec[k], md.dD[k]));
-            }
+            for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.dgrad_hidden(md.dD[k], md.dec[k], md.D[k - 1], md.dD[k - 1]));
         });
-    group("bwd_dec1_latent", h->bwd, [&] {
-        for (Mod& md : h->mods) {
-            h->items.push_back(bd.dgrad_latent(md));
-            h->items.push_back(bd.wgrad(md.Z, md.dec[0], md.dD[0]));
-        }
-    });
+    group("bwd_dec1_latent", h->bwd, [&] { for (Mod& md : h->mods) h->items.push_back(bd.dgrad_latent(md)); });
     group("bwd_head", h->bwd, [&] {
-        for (Mod& md : h->mods) {
-            h->items.push_back(bd.dgrad_hidden(md.dH, md.head, md.E.back(), md.dE.back()));
-            h->items.push_back(bd.wgrad(md.E.back(), md.head, md.dH));
-        }
+        for (Mod& md : h->mods) h->items.push_back(bd.dgrad_hidden(md.dH, md.head, md.E.back(), md.dE.back()));
+        if (Lmax == 1) h->items.push_back(bd.cost(true));
     });
     for (int k = Lmax - 1; k >= 1; --k)
         group("bwd_enc" + std::to_string(k + 1), h->bwd, [&] {
-            for (Mod& md : h->mods) if (k < md.L) {
-                h->items.push_back(bd.dgrad_hidden(md.dE[k], md.enc[k], md.E[k - 1], md.dE[k - 1]));
-                h->items.push_back(bd.wgrad(md.E[k - 1], md.enc[k], md.dE[k]));
-            }
+            for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.dgrad_hidden(md.dE[k], md.enc[k], md.E[k - 1], md.dE[k - 1]));
+            if (k == 1) h->items.push_back(bd.cost(true));       // last launch of the chain: cost, step counter, lr_t
         });
-    group("bwd_enc1", h->bwd, [&] {
-        for (Mod& md : h->mods) h->items.push_back(bd.wgrad(md.X0, md.enc[0], md.dE[0]));
-        h->items.push_back(bd.cost(true));
-    });
+    for (int fused = 0; fused < 2; ++fused) {
+        std::vector<WorkItem> wg;
+        for (Mod& md : h->mods) {
+            wg.push_back(bd.wgrad(md.D.back(), md.outl, md.dO, fused));
+            for (int k = md.L - 1; k >= 1; --k) wg.push_back(bd.wgrad(md.D[k - 1], md.dec[k], md.dD[k], fused));
+            wg.push_back(bd.wgrad(md.Z, md.dec[0], md.dD[0], fused));
+            wg.push_back(bd.wgrad(md.E.back(), md.head, md.dH, fused));
+            for (int k = md.L - 1; k >= 1; --k) wg.push_back(bd.wgrad(md.E[k - 1], md.enc[k], md.dE[k], fused));
+            wg.push_back(bd.wgrad(md.X0, md.enc[0], md.dE[0], fused));
+        }
+        std::vector<Launch>& dst = fused ? h->wg_adam : h->wg_plain;
+        dst.clear();
+        for (size_t i0 = 0; i0 < wg.size(); i0 += kMaxItemsPerLaunch) {
+            const size_t i1 = std::min(wg.size(), i0 + kMaxItemsPerLaunch);
+            group(std::string(fused ? "wgrad_adam" : "wgrad") + (wg.size() > (size_t)kMaxItemsPerLaunch ? std::to_string(i0 / kMaxItemsPerLaunch + 1) : ""),
+                  dst, [&] { for (size_t i = i0; i < i1; ++i) h->items.push_back(wg[i]); });
+        }
+    }
     // ---- eval: forward launches + a lone cost reduction that does not bump the step
     {
         const int first = (int)h->items.size();
@@ -657,9 +669,12 @@ void init_device(avae_handle* h) {
     if (h->cfg.use_graph) {
         const bool tsave = h->timing;
         h->timing = false;
-        h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, h->bwd, cs); });
+        h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, h->bwd, cs); run_launches(h, h->wg_plain, cs); });
         h->g_adam = capture(h, [&](hipStream_t cs) { run_adam(h, 0, cs); });
-        h->g_full = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs, 0); run_launches(h, h->bwd, cs, (int)h->fwd.size()); run_adam(h, 0, cs); });
+        h->g_full = capture(h, [&](hipStream_t cs) {
+            run_launches(h, h->fwd, cs, 0); run_launches(h, h->bwd, cs, (int)h->fwd.size());
+            run_launches(h, h->wg_adam, cs, (int)(h->fwd.size() + h->bwd.size()));
+        });
         h->g_eval = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, std::vector<Launch>{h->cost_only}, cs); });
         h->timing = tsave;
     }
@@ -667,7 +682,7 @@ void init_device(avae_handle* h) {
 
 void do_backward(avae_handle* h, hipStream_t s) {
     if (h->g_bwd && !h->timing) HIP_OK(hipGraphLaunch(h->g_bwd, s));
-    else { run_launches(h, h->fwd, s); run_launches(h, h->bwd, s); }
+    else { run_launches(h, h->fwd, s); run_launches(h, h->bwd, s); run_launches(h, h->wg_plain, s); }
 }
 
 void do_apply(avae_handle* h, hipStream_t s) {
@@ -842,8 +857,9 @@ int avae_train_step(avae_handle* h, const float* const* x_dev, const int32_t* x_
     return guarded(h, [&] {
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, s);
+        // single replica: Adam rides in the epilogue of the weight-gradient launches
         if (h->g_full && !h->timing) HIP_OK(hipGraphLaunch(h->g_full, s));
-        else { do_backward(h, s); do_apply(h, s); }
+        else { run_launches(h, h->fwd, s); run_launches(h, h->bwd, s); run_launches(h, h->wg_adam, s); }
         fetch_cost(h, cost_host, true, s);
     });
 }

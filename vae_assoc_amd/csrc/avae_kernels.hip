@@ -237,6 +237,73 @@ __device__ __forceinline__ void transposed_store(const float* Cs, OT* out, int l
     }
 }
 
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* v, int nvalid);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* v, int nvalid) {
+    store_row<float>(p, v, nvalid);
+    if (nvalid > 4) store_row<float>(p + 4, v + 4, nvalid - 4);
+}
+template <> __device__ __forceinline__ void store8<__bf16>(__bf16* p, const float* v, int nvalid) { store_vec<__bf16, 8>(p, v, nvalid); }
+
+// K_WGRAD_ADAM epilogue: the fp32 gradient tile is in LDS; apply TF-1 Adam (vae_assoc.py:373-374:
+// m += (g-m)(1-b1); v += (g^2-v)(1-b2); theta -= lr_t m/(sqrt(v)+eps)) to the matching tile of
+// theta/m/v and refresh both compute-dtype shadows, so no separate optimiser kernel and no
+// gradient round trip through HBM is needed on a single replica.  Pointers: out0 = g (still
+// written: avae_get_grads), out1 = W shadow, out2 = W^T shadow, aux0/1/2 = theta/m/v.
+template <typename CT, int BM, int BN>
+__device__ __forceinline__ void wgrad_adam_pass(float* Cs, const WorkItem& w, float lr_t, int m0, int n0) {
+    constexpr int LDC = BN + 4, QC = BN / 8, NQ = BM * QC / kThreads;
+    const int tid = threadIdx.x, M = w.M, N = w.N, ld = w.ld0;
+    float* G = reinterpret_cast<float*>(w.out0);
+    float* TH = reinterpret_cast<float*>(const_cast<void*>(w.aux0));
+    float* MM = reinterpret_cast<float*>(const_cast<void*>(w.aux1));
+    float* VV = reinterpret_cast<float*>(const_cast<void*>(w.aux2));
+    CT* W = reinterpret_cast<CT*>(w.out1);
+    const float omb1 = 1.0f - w.scale, omb2 = 1.0f - w.lambda, aeps = w.inv_bg;
+    float g[NQ][8], th[NQ][8], mm[NQ][8], vv[NQ][8];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + row * LDC + c0 + 4 * h);
+            g[q][4 * h] = t[0]; g[q][4 * h + 1] = t[1]; g[q][4 * h + 2] = t[2]; g[q][4 * h + 3] = t[3];
+        }
+        const size_t off = (size_t)min(m0 + row, M - 1) * ld + min(n0 + c0, ld - 8);     // clamped => never stored
+        load_vec<float, 8>(TH + off, th[q]);
+        load_vec<float, 8>(MM + off, mm[q]);
+        load_vec<float, 8>(VV + off, vv[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            mm[q][e] += (g[q][e] - mm[q][e]) * omb1;
+            vv[q][e] += (g[q][e] * g[q][e] - vv[q][e]) * omb2;
+            th[q][e] -= (mm[q][e] * lr_t) / (sqrtf(vv[q][e]) + aeps);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<f32x4*>(Cs + row * LDC + c0 + 4 * h) = f32x4{th[q][4 * h], th[q][4 * h + 1], th[q][4 * h + 2], th[q][4 * h + 3]};
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
+        const int grow = m0 + row, gcol = n0 + c0;
+        if (grow < M && gcol < N) {
+            const size_t off = (size_t)grow * ld + gcol;
+            const int nv = N - gcol;
+            store8<float>(G + off, g[q], nv);
+            store8<float>(TH + off, th[q], nv);
+            store8<float>(MM + off, mm[q], nv);
+            store8<float>(VV + off, vv[q], nv);
+            store8<CT>(W + off, th[q], nv);
+        }
+    }
+    lds_barrier();
+    transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out2), w.ld2, M, N, m0, n0);
+}
+
 // ------------------------------------------------------------------ non-GEMM work items
 // KL(q||N(0,I)) (vae_assoc.py:335-337) and the symmetric-KL association penalty (:346-366) with
 // their gradients w.r.t. (mu, lv).  The log-determinant terms of the two directed KLs cancel, so
@@ -316,6 +383,8 @@ __device__ void cost_item(const WorkItem& w, DevState* st, float* red) {
             // TF-1 Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), published for the Adam kernel of this step
             const double b1t = pow((double)w.lambda, (double)tnew), b2t = pow((double)w.inv_bg, (double)tnew);
             st->lr_t = (float)((double)w.scale * sqrt(1.0 - b2t) / (1.0 - b1t));
+            st->last_cost = total;                                   // local cost; the multi-replica path
+            st->cost_hist[(tnew - 1) % kCostHist] = total;           // overwrites it with the all-reduced one
         }
     }
 }
@@ -352,7 +421,18 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const LaunchArgs args, Dev
     for (int i = 1; i < kMaxItemsPerLaunch; ++i)
         if (i < args.n_items && bid >= args.base[i]) it = i;     // bases ascend; everything is a kernel argument
     const WorkItem w = args.items[it];                            // one burst of scalar loads from the kernarg segment
-    const int t = bid - w.tile_base;
+    // XCD-aware tile order inside the item: hardware deals workgroups round-robin over the 8 XCDs
+    // (private 4 MiB L2 each) and item bases are multiples of 8, so local%8 names the XCD group.
+    // Each group gets one contiguous chunk of the item's tile list (tiles that share A row panels /
+    // B column panels meet in one L2); every item is still spread over all XCDs, which keeps heavy
+    // and light items balanced.  Bijective for any tile count; only speed depends on it.
+    int t;
+    {
+        const int local = bid - w.tile_base, nt = w.tiles_m * w.tiles_n;
+        const int q = nt >> 3, r = nt & 7, xcd = local & 7, j = local >> 3;
+        if (j >= q + (xcd < r ? 1 : 0)) return;                   // padding block behind the item's last tile
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
     if (w.kind == K_LATENT) { latent_item(w, t, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
     if (w.kind == K_COST) { cost_item(w, st, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
 
@@ -586,6 +666,9 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const LaunchArgs args, Dev
         float* G = reinterpret_cast<float*>(w.out0);
         tile_pass<float, float, false, false, BM, BN>(Cs, G, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
             [](float c, float, bool) { return c; });
+    } break;
+    case K_WGRAD_ADAM: {
+        wgrad_adam_pass<CT, BM, BN>(Cs, w, st->lr_t, m0, n0);
     } break;
     default: break;
     }
