@@ -68,7 +68,7 @@ struct Mod {
 
 struct Launch {
     std::string name;
-    int cfg = 0, first = 0, count = 0, blocks = 0;
+    int cfg = 0, first = 0, count = 0, blocks = 0, lds = 0;
     LaunchArgs args{};
 };
 
@@ -406,6 +406,11 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         }
     }
     L.blocks = base;
+    {
+        bool two = false;
+        for (int i = first; i < first + count; ++i) two = two || items[i].kind == K_FWD_HEAD || items[i].kind == K_DGRAD_LATENT;
+        L.lds = tile_lds_bytes(L.cfg, two);
+    }
     if (count > kMaxItemsPerLaunch) throw Err("internal error: too many items in one launch");
     std::memset(&L.args, 0, sizeof(L.args));
     L.args.n_items = count;
@@ -424,7 +429,8 @@ void build_training_plan(avae_handle* h) {
         const int first = (int)h->items.size();
         fill();
         const int count = (int)h->items.size() - first;
-        if (count > 0) dst.push_back(finish_launch(h, h->items, first, count, name, &slot));
+        if (count <= 0) return;
+        dst.push_back(finish_launch(h, h->items, first, count, name, &slot));
     };
     // ---- forward.  Modalities with fewer hidden layers simply sit out a launch; data dependencies
     // are per modality and launches are stream-ordered, so this is always safe.
@@ -559,7 +565,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
 #ifdef AVAE_STAMPS
         if (stamp_base >= 0) stamps = h->at<unsigned long long>(h->off_stamps);
 #endif
-        launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.blocks, h->state(), s, stamps, stamp_base + k);
+        launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.blocks, L.lds, h->state(), s, stamps, stamp_base + k);
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to
             std::fprintf(stderr, "[avae] launch %s cfg=%d items=%d blocks=%d\n", L.name.c_str(), L.cfg, L.count, L.blocks);
             std::fflush(stderr);

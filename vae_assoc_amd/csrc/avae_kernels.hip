@@ -91,6 +91,10 @@ template <> __device__ __forceinline__ void store_vec<__bf16, 8>(__bf16* p, cons
 
 template <typename CT> __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c);
 template <> __device__ __forceinline__ void mma<__bf16>(const u32x4& a, const u32x4& b, f32x4& c) {
+#ifdef AVAE_ABL_NO_MFMA     /* diagnostic: keep the operands live, skip the matrix pipe (results are garbage) */
+    asm volatile("" ::"v"(a), "v"(b));
+    return;
+#endif
     // lane l: A[row l&15][k 8*(l>>4)..+7], B[k 8*(l>>4)..+7][col l&15]; C col l&15, row 4*(l>>4)+reg
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -169,6 +173,12 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Index of element (r, c) of an fp32 accumulator tile in LDS (row stride LDC = BN + 4).  Columns are
+// XOR-swizzled by the row's 8-row group in units of 4 floats: a row access (16-B groups) stays
+// aligned and contiguous per group, while the column walk of the transposed store -- lanes 8 rows
+// apart, 8*LDC = 0 mod 32 banks, i.e. all on ONE bank unswizzled -- spreads over 8 banks.
+template <int LDC> __device__ __forceinline__ int cs_idx(int r, int c) { return r * LDC + (c ^ (((r >> 3) & 7) << 2)); }
+
 // ------------------------------------------------------------------ epilogue passes
 // The accumulator tile sits in LDS as fp32 [BM][BN+4].  A pass is written in three phases so that
 // all of a thread's LDS reads and auxiliary global loads are in flight together (no per-quad
@@ -179,61 +189,69 @@ template <typename OT, typename AT, bool HAS_AUX, bool WRITEBACK, int BM, int BN
 __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT* aux, int ldx,
                                           int M, int N, int m0, int n0, Op op) {
     constexpr int VW = Vec16<OT>::VW;                     // elements per 16-byte store
-    constexpr int LDC = BN + 4, QC = BN / VW, NQ = BM * QC / kThreads;
+    constexpr int LDC = BN + 4, QC = BN / VW, NQT = BM * QC / kThreads;
+    constexpr int NQ = NQT < 32 / VW ? NQT : 32 / VW;     // groups handled together: <= 32 elements per array in flight
+    static_assert(NQT % NQ == 0, "tile / thread mapping");
     const int tid = threadIdx.x;
-    float c[NQ][VW], a[NQ][VW];
+    for (int q0 = 0; q0 < NQT; q0 += NQ) {
+        float c[NQ][VW], a[NQ][VW];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
 #pragma unroll
-        for (int h = 0; h < VW / 4; ++h) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + row * LDC + c0 + 4 * h);
-            c[q][4 * h] = t[0]; c[q][4 * h + 1] = t[1]; c[q][4 * h + 2] = t[2]; c[q][4 * h + 3] = t[3];
+            for (int h = 0; h < VW / 4; ++h) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + cs_idx<LDC>(row, c0 + 4 * h));
+                c[q][4 * h] = t[0]; c[q][4 * h + 1] = t[1]; c[q][4 * h + 2] = t[2]; c[q][4 * h + 3] = t[3];
+            }
+            if (HAS_AUX) {
+                const int gr = min(m0 + row, M - 1), gc = min(n0 + c0, ldx - VW);   // clamped => that group is never stored
+                load_vec<AT, VW>(aux + (size_t)gr * ldx + gc, a[q]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VW; ++e) a[q][e] = 0.0f;
+            }
         }
-        if (HAS_AUX) {
-            const int gr = min(m0 + row, M - 1), gc = min(n0 + c0, ldx - VW);   // clamped => that group is never stored
-            load_vec<AT, VW>(aux + (size_t)gr * ldx + gc, a[q]);
-        } else {
 #pragma unroll
-            for (int e = 0; e < VW; ++e) a[q][e] = 0.0f;
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
+            const bool rok = m0 + row < M;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) c[q][e] = op(c[q][e], a[q][e], rok && (n0 + c0 + e < N));
+            if (WRITEBACK) {
+#pragma unroll
+                for (int h = 0; h < VW / 4; ++h)
+                    *reinterpret_cast<f32x4*>(Cs + cs_idx<LDC>(row, c0 + 4 * h)) = f32x4{c[q][4 * h], c[q][4 * h + 1], c[q][4 * h + 2], c[q][4 * h + 3]};
+            }
         }
-    }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
-        const bool rok = m0 + row < M;
-#pragma unroll
-        for (int e = 0; e < VW; ++e) c[q][e] = op(c[q][e], a[q][e], rok && (n0 + c0 + e < N));
-        if (WRITEBACK) {
-#pragma unroll
-            for (int h = 0; h < VW / 4; ++h)
-                *reinterpret_cast<f32x4*>(Cs + row * LDC + c0 + 4 * h) = f32x4{c[q][4 * h], c[q][4 * h + 1], c[q][4 * h + 2], c[q][4 * h + 3]};
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
+            const int grow = m0 + row, gcol = n0 + c0;
+            if (grow < M && gcol < N) store_vec<OT, VW>(out + (size_t)grow * ld0 + gcol, c[q], N - gcol);
         }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
-        const int grow = m0 + row, gcol = n0 + c0;
-        if (grow < M && gcol < N) store_vec<OT, VW>(out + (size_t)grow * ld0 + gcol, c[q], N - gcol);
     }
 }
 
 template <typename OT, int BM, int BN>
 __device__ __forceinline__ void transposed_store(const float* Cs, OT* out, int ld, int M, int N, int m0, int n0) {
     constexpr int VW = Vec16<OT>::VW;
-    constexpr int LDC = BN + 4, QR = BM / VW, NQ = BN * QR / kThreads;
-    float v[NQ][VW];
+    constexpr int LDC = BN + 4, QR = BM / VW, NQT = BN * QR / kThreads;
+    constexpr int NQ = NQT < 32 / VW ? NQT : 32 / VW;
+    static_assert(NQT % NQ == 0, "tile / thread mapping");
+    for (int q0 = 0; q0 < NQT; q0 += NQ) {
+        float v[NQ][VW];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int idx = threadIdx.x + q * kThreads, col = idx / QR, r0 = (idx - col * QR) * VW;
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = threadIdx.x + (q0 + q) * kThreads, col = idx / QR, r0 = (idx - col * QR) * VW;
 #pragma unroll
-        for (int e = 0; e < VW; ++e) v[q][e] = Cs[(r0 + e) * LDC + col];
-    }
+            for (int e = 0; e < VW; ++e) v[q][e] = Cs[cs_idx<LDC>(r0 + e, col)];
+        }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int idx = threadIdx.x + q * kThreads, col = idx / QR, r0 = (idx - col * QR) * VW;
-        const int gcol = n0 + col, grow = m0 + r0;
-        if (gcol < N && grow < M) store_vec<OT, VW>(out + (size_t)gcol * ld + grow, v[q], M - grow);
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = threadIdx.x + (q0 + q) * kThreads, col = idx / QR, r0 = (idx - col * QR) * VW;
+            const int gcol = n0 + col, grow = m0 + r0;
+            if (gcol < N && grow < M) store_vec<OT, VW>(out + (size_t)gcol * ld + grow, v[q], M - grow);
+        }
     }
 }
 
@@ -251,7 +269,9 @@ template <> __device__ __forceinline__ void store8<__bf16>(__bf16* p, const floa
 // written: avae_get_grads), out1 = W shadow, out2 = W^T shadow, aux0/1/2 = theta/m/v.
 template <typename CT, int BM, int BN>
 __device__ __forceinline__ void wgrad_adam_pass(float* Cs, const WorkItem& w, float lr_t, int m0, int n0) {
-    constexpr int LDC = BN + 4, QC = BN / 8, NQ = BM * QC / kThreads;
+    constexpr int LDC = BN + 4, QC = BN / 8, NQT = BM * QC / kThreads;
+    constexpr int NQ = 2;                      // octets per thread handled together (bounds the register footprint)
+    static_assert(NQT % NQ == 0, "tile / thread mapping");
     const int tid = threadIdx.x, M = w.M, N = w.N, ld = w.ld0;
     float* G = reinterpret_cast<float*>(w.out0);
     float* TH = reinterpret_cast<float*>(const_cast<void*>(w.aux0));
@@ -259,45 +279,47 @@ __device__ __forceinline__ void wgrad_adam_pass(float* Cs, const WorkItem& w, fl
     float* VV = reinterpret_cast<float*>(const_cast<void*>(w.aux2));
     CT* W = reinterpret_cast<CT*>(w.out1);
     const float omb1 = 1.0f - w.scale, omb2 = 1.0f - w.lambda, aeps = w.inv_bg;
-    float g[NQ][8], th[NQ][8], mm[NQ][8], vv[NQ][8];
+    for (int q0 = 0; q0 < NQT; q0 += NQ) {
+        float g[NQ][8], th[NQ][8], mm[NQ][8], vv[NQ][8];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + row * LDC + c0 + 4 * h);
-            g[q][4 * h] = t[0]; g[q][4 * h + 1] = t[1]; g[q][4 * h + 2] = t[2]; g[q][4 * h + 3] = t[3];
-        }
-        const size_t off = (size_t)min(m0 + row, M - 1) * ld + min(n0 + c0, ld - 8);     // clamped => never stored
-        load_vec<float, 8>(TH + off, th[q]);
-        load_vec<float, 8>(MM + off, mm[q]);
-        load_vec<float, 8>(VV + off, vv[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            mm[q][e] += (g[q][e] - mm[q][e]) * omb1;
-            vv[q][e] += (g[q][e] * g[q][e] - vv[q][e]) * omb2;
-            th[q][e] -= (mm[q][e] * lr_t) / (sqrtf(vv[q][e]) + aeps);
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + cs_idx<LDC>(row, c0 + 4 * h));
+                g[q][4 * h] = t[0]; g[q][4 * h + 1] = t[1]; g[q][4 * h + 2] = t[2]; g[q][4 * h + 3] = t[3];
+            }
+            const size_t off = (size_t)min(m0 + row, M - 1) * ld + min(n0 + c0, ld - 8);     // clamped => never stored
+            load_vec<float, 8>(TH + off, th[q]);
+            load_vec<float, 8>(MM + off, mm[q]);
+            load_vec<float, 8>(VV + off, vv[q]);
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-            *reinterpret_cast<f32x4*>(Cs + row * LDC + c0 + 4 * h) = f32x4{th[q][4 * h], th[q][4 * h + 1], th[q][4 * h + 2], th[q][4 * h + 3]};
-    }
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int idx = tid + q * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
-        const int grow = m0 + row, gcol = n0 + c0;
-        if (grow < M && gcol < N) {
-            const size_t off = (size_t)grow * ld + gcol;
-            const int nv = N - gcol;
-            store8<float>(G + off, g[q], nv);
-            store8<float>(TH + off, th[q], nv);
-            store8<float>(MM + off, mm[q], nv);
-            store8<float>(VV + off, vv[q], nv);
-            store8<CT>(W + off, th[q], nv);
+            for (int e = 0; e < 8; ++e) {
+                mm[q][e] += (g[q][e] - mm[q][e]) * omb1;
+                vv[q][e] += (g[q][e] * g[q][e] - vv[q][e]) * omb2;
+                th[q][e] -= (mm[q][e] * lr_t) / (sqrtf(vv[q][e]) + aeps);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                *reinterpret_cast<f32x4*>(Cs + cs_idx<LDC>(row, c0 + 4 * h)) = f32x4{th[q][4 * h], th[q][4 * h + 1], th[q][4 * h + 2], th[q][4 * h + 3]};
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
+            const int grow = m0 + row, gcol = n0 + c0;
+            if (grow < M && gcol < N) {
+                const size_t off = (size_t)grow * ld + gcol;
+                const int nv = N - gcol;
+                store8<float>(G + off, g[q], nv);
+                store8<float>(TH + off, th[q], nv);
+                store8<float>(MM + off, mm[q], nv);
+                store8<float>(VV + off, vv[q], nv);
+                store8<CT>(W + off, th[q], nv);
+            }
         }
     }
     lds_barrier();
@@ -371,7 +393,7 @@ __device__ __forceinline__ void latent_item(const WorkItem& w, int t, float* red
     if (threadIdx.x == 0) w.partial[w.slot_base + t] = total;
 }
 
-__device__ void cost_item(const WorkItem& w, DevState* st, float* red) {
+__device__ __forceinline__ void cost_item(const WorkItem& w, DevState* st, float* red) {
     float s = 0.0f;
     for (int i = threadIdx.x; i < w.n_slots; i += kThreads) s += w.partial[i];
     const float total = block_sum(s, red);
@@ -390,20 +412,29 @@ __device__ void cost_item(const WorkItem& w, DevState* st, float* red) {
 }
 
 // ------------------------------------------------------------------ the grouped kernel
-constexpr int kRing = 4;                    // LDS ring depth: up to 3 K tiles in flight behind the one being multiplied
-template <int BM, int BN> struct TileSmem {
+// LDS budget of one workgroup: a ring of RING linear K-tile stages, re-used by the epilogue as one
+// (or, for the head / latent kinds, two) fp32 accumulator tiles.  Passed as dynamic LDS so that a
+// launch only pays for what its kinds need: 64x64 tiles keep 4 stages (up to 3 K tiles in flight,
+// the small-batch case is latency-bound); 128x128 tiles keep 2 stages = 66 KiB so that TWO
+// workgroups share a CU and one's MFMA phase covers the other's barrier / DMA wait.
+template <int BM, int BN, int RING> struct TileSmem {
     static constexpr int kStage = (BM + BN) * kTileBytesK;     // linear 128-B rows (LDS-DMA image), XOR-swizzled chunks
-    static constexpr int kStages = kRing * kStage;
-    static constexpr int kC = BM * (BN + 4) * 4;          // fp32 accumulator tile; the latent epilogues use a second one
-    static constexpr int kMain = kStages > 2 * kC ? kStages : 2 * kC;
-    static constexpr int kTotal = kMain + 64;
+    static constexpr int kStages = RING * kStage;
+    static constexpr int kC = BM * (BN + 4) * 4;               // one fp32 accumulator tile
 };
+int tile_lds_bytes(int tile_cfg, bool two_c_tiles) {
+    const int stages = tile_cfg ? TileSmem<128, 128, 2>::kStages : TileSmem<64, 64, 4>::kStages;
+    const int c = (tile_cfg ? TileSmem<128, 128, 2>::kC : TileSmem<64, 64, 4>::kC) * (two_c_tiles ? 2 : 1);
+    return (stages > c ? stages : c) + 64;                     // + block-reduction scratch
+}
 
-template <typename CT, int BM, int BN>
-__global__ void __launch_bounds__(kThreads) k_grouped(const LaunchArgs args, DevState* st,
+extern __shared__ __attribute__((aligned(16))) unsigned char avae_dyn_smem[];
+
+template <typename CT, int BM, int BN, int RING>
+__global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const LaunchArgs args, DevState* st, int lds_bytes,
                                                       unsigned long long* stamps, int launch_id) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[TileSmem<BM, BN>::kTotal];
-    float* red = reinterpret_cast<float*>(smem + TileSmem<BM, BN>::kMain);
+    unsigned char* smem = avae_dyn_smem;
+    float* red = reinterpret_cast<float*>(smem + lds_bytes - 64);
 #ifdef AVAE_STAMPS
     unsigned long long sv[kStampWords] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define AVAE_STAMP(i) { __builtin_amdgcn_sched_barrier(0); sv[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
@@ -486,37 +517,54 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const LaunchArgs args, Dev
     {                                                                                                  \
         _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                                \
             __builtin_amdgcn_global_load_lds((gp_t)(src[c] + (size_t)(kt) * kTileBytesK),              \
-                (lp_t)(smem + (buf) * TileSmem<BM, BN>::kStage + (c * 4 + wave_u) * 1024), 16, 0, 0);  \
+                (lp_t)(smem + (buf) * TileSmem<BM, BN, RING>::kStage + (c * 4 + wave_u) * 1024), 16, 0, 0);  \
     }
 #define AVAE_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-#define AVAE_COMPUTE(buf)                                                                              \
+#ifdef AVAE_ABL_NO_DMA      /* diagnostic: loop without the operand refills (results are garbage) */
+#define AVAE_ABL_DMA(kt, buf)
+#else
+#define AVAE_ABL_DMA(kt, buf) AVAE_DMA(kt, buf)
+#endif
+    // The refill DMA of the stage freed by the previous tile is issued between the first slab's
+    // fragment reads and its MFMAs, so the issue cost (~60-100 cycles per 1-KiB piece) overlaps
+    // matrix-pipe work instead of preceding it.
+#define AVAE_COMPUTE(buf, do_dma, dma_kt, dma_buf)                                                     \
     {                                                                                                  \
-        const unsigned char* Sb = smem + (buf) * TileSmem<BM, BN>::kStage;                             \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                \
-            u32x4 a[MI], b[NI];                                                                        \
-            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                             \
-                a[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + (sw0 ^ (s * 64)));  \
-            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                             \
-                b[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + (sw0 ^ (s * 64)));  \
-            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                             \
-                _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a[i], b[j], acc[i][j]);         \
-        }                                                                                              \
+        const unsigned char* Sb = smem + (buf) * TileSmem<BM, BN, RING>::kStage;                       \
+        u32x4 a[MI], b[NI];                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
+            a[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + sw0);            \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
+            b[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + sw0);            \
+        if (do_dma) AVAE_ABL_DMA(dma_kt, dma_buf)                                                      \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a[i], b[j], acc[i][j]);             \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
+            a[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + (sw0 ^ 64));     \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
+            b[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + (sw0 ^ 64));     \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a[i], b[j], acc[i][j]);             \
     }
 
     AVAE_STAMP(1)
     {
-        const int npro = nk < kRing - 1 ? nk : kRing - 1;
+        const int npro = nk < RING - 1 ? nk : RING - 1;
         for (int p = 0; p < npro; ++p) AVAE_DMA(p, p)
     }
     for (int kt = 0; kt < nk; ++kt) {
-        const int rem = nk - 1 - kt;           // tiles issued behind kt: min(rem, kRing - 2)
-        if (rem >= 2) AVAE_WAIT(2 * NCH);
-        else if (rem == 1) AVAE_WAIT(NCH);
-        else AVAE_WAIT(0);
+        if constexpr (RING == 2) {
+            AVAE_WAIT(0);
+        } else {
+            static_assert(RING == 4, "wait ladder written for RING 2 and 4");
+            const int rem = nk - 1 - kt;       // tiles issued behind kt: min(rem, RING - 2)
+            if (rem >= 2) AVAE_WAIT(2 * NCH);
+            else if (rem == 1) AVAE_WAIT(NCH);
+            else AVAE_WAIT(0);
+        }
         asm volatile("s_barrier" ::: "memory");
         if (kt == 0) { AVAE_STAMP(2) }
-        if (kt + kRing - 1 < nk) AVAE_DMA(kt + kRing - 1, (kt + kRing - 1) & (kRing - 1))
-        AVAE_COMPUTE(kt & (kRing - 1))
+        AVAE_COMPUTE(kt & (RING - 1), kt + RING - 1 < nk, kt + RING - 1, (kt + RING - 1) & (RING - 1))
     }
     lds_barrier();
     AVAE_STAMP(3)
@@ -534,7 +582,7 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const LaunchArgs args, Dev
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    Cs[(wr * WM + i * 16 + fq * 4 + r) * LDC + wc * WN + j * 16 + fr] = acc[i][j][r];
+                    Cs[cs_idx<LDC>(wr * WM + i * 16 + fq * 4 + r, wc * WN + j * 16 + fr)] = acc[i][j][r];
     }
     lds_barrier();
     AVAE_STAMP(5)
@@ -558,17 +606,19 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const LaunchArgs args, Dev
         float* Zs = Cs + BM * LDC;                         // second fp32 tile: z
         const float* eps = reinterpret_cast<const float*>(w.aux0);
         if (w.out1) {
-            constexpr int NI = BM * (BN / 2) / kThreads;   // nz <= BN/2
-            float ev[NI];
+            constexpr int NI = 8;                           // elements per thread handled together
+            for (int i0 = tid; i0 < BM * nz; i0 += NI * kThreads) {
+                float ev[NI];
 #pragma unroll
-            for (int q = 0; q < NI; ++q) {
-                const int idx = tid + q * kThreads, row = idx / nz, d = idx - row * nz;
-                ev[q] = (idx < BM * nz) ? eps[(size_t)min(m0 + row, M - 1) * w.ldx + d] : 0.0f;
-            }
+                for (int q = 0; q < NI; ++q) {
+                    const int idx = i0 + q * kThreads, row = idx / nz, d = idx - row * nz;
+                    ev[q] = (idx < BM * nz) ? eps[(size_t)min(m0 + row, M - 1) * w.ldx + d] : 0.0f;
+                }
 #pragma unroll
-            for (int q = 0; q < NI; ++q) {
-                const int idx = tid + q * kThreads, row = idx / nz, d = idx - row * nz;
-                if (idx < BM * nz) Zs[row * LDC + d] = Cs[row * LDC + d] + fexp(0.5f * Cs[row * LDC + nz + d]) * ev[q];
+                for (int q = 0; q < NI; ++q) {
+                    const int idx = i0 + q * kThreads, row = idx / nz, d = idx - row * nz;
+                    if (idx < BM * nz) Zs[cs_idx<LDC>(row, d)] = Cs[cs_idx<LDC>(row, d)] + fexp(0.5f * Cs[cs_idx<LDC>(row, nz + d)]) * ev[q];
+                }
             }
         }
         tile_pass<float, float, false, false, BM, BN>(Cs, reinterpret_cast<float*>(w.out0), w.ld0, (const float*)nullptr, 4,
@@ -638,22 +688,24 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const LaunchArgs args, Dev
         float* Zs = Cs + BM * LDC;
         const float* g0 = reinterpret_cast<const float*>(w.aux2);
         {
-            constexpr int NI = BM * (BN / 2) / kThreads;
-            float gm[NI], gl[NI], gf[NI];
+            constexpr int NI = 8;
+            for (int i0 = tid; i0 < BM * nz; i0 += NI * kThreads) {
+                float gm[NI], gl[NI], gf[NI];
 #pragma unroll
-            for (int q = 0; q < NI; ++q) {
-                const int idx = tid + q * kThreads, row = idx / nz, d = idx - row * nz;
-                const size_t o = (size_t)min(m0 + row, M - 1) * 3 * nz + d;
-                const bool ok = idx < BM * nz;
-                gm[q] = ok ? g0[o] : 0.0f; gl[q] = ok ? g0[o + nz] : 0.0f; gf[q] = ok ? g0[o + 2 * nz] : 0.0f;
-            }
+                for (int q = 0; q < NI; ++q) {
+                    const int idx = i0 + q * kThreads, row = idx / nz, d = idx - row * nz;
+                    const size_t o = (size_t)min(m0 + row, M - 1) * 3 * nz + d;
+                    const bool ok = idx < BM * nz;
+                    gm[q] = ok ? g0[o] : 0.0f; gl[q] = ok ? g0[o + nz] : 0.0f; gf[q] = ok ? g0[o + 2 * nz] : 0.0f;
+                }
 #pragma unroll
-            for (int q = 0; q < NI; ++q) {
-                const int idx = tid + q * kThreads, row = idx / nz, d = idx - row * nz;
-                if (idx < BM * nz) {
-                    const float dz = Cs[row * LDC + d];
-                    Zs[row * LDC + d] = dz + gm[q];
-                    Zs[row * LDC + nz + d] = dz * gf[q] + gl[q];
+                for (int q = 0; q < NI; ++q) {
+                    const int idx = i0 + q * kThreads, row = idx / nz, d = idx - row * nz;
+                    if (idx < BM * nz) {
+                        const float dz = Cs[cs_idx<LDC>(row, d)];
+                        Zs[cs_idx<LDC>(row, d)] = dz + gm[q];
+                        Zs[cs_idx<LDC>(row, nz + d)] = dz * gf[q] + gl[q];
+                    }
                 }
             }
         }
@@ -676,15 +728,26 @@ __global__ void __launch_bounds__(kThreads) k_grouped(const LaunchArgs args, Dev
     AVAE_STAMP_FLUSH()
 }
 
-void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int n_blocks,
+template <typename K> static void set_max_lds(K kernel) {
+    // > 64 KiB of dynamic LDS has to be opted into once per kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int n_blocks, int lds_bytes,
                     DevState* st, hipStream_t s, unsigned long long* stamps, int launch_id) {
+    static const bool once = [] {
+        set_max_lds(k_grouped<__bf16, 64, 64, 4>); set_max_lds(k_grouped<__bf16, 128, 128, 2>);
+        set_max_lds(k_grouped<float, 64, 64, 4>); set_max_lds(k_grouped<float, 128, 128, 2>);
+        return true;
+    }();
+    (void)once;
     dim3 grid(n_blocks), block(kThreads);
     if (compute_dtype == AVAE_BF16) {
-        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<__bf16, 64, 64>), grid, block, 0, s, args, st, stamps, launch_id);
-        else hipLaunchKernelGGL((k_grouped<__bf16, 128, 128>), grid, block, 0, s, args, st, stamps, launch_id);
+        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<__bf16, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+        else hipLaunchKernelGGL((k_grouped<__bf16, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
     } else {
-        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<float, 64, 64>), grid, block, 0, s, args, st, stamps, launch_id);
-        else hipLaunchKernelGGL((k_grouped<float, 128, 128>), grid, block, 0, s, args, st, stamps, launch_id);
+        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<float, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+        else hipLaunchKernelGGL((k_grouped<float, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
     }
 }
 
