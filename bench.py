@@ -241,7 +241,11 @@ def main():
             else:
                 ach = by / avg_s / 1e9
                 roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
-            roof.update({"traffic": None, "kernel": dom, "avg_us": round(kern[dom][1] * 1e3, 2),
+            traffic = None        # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+            tf = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % args.config)
+            if os.path.exists(tf):
+                traffic = json.load(open(tf))["launches"].get(dom, {}).get("hbm_bytes")
+            roof.update({"traffic": traffic, "kernel": dom, "avg_us": round(kern[dom][1] * 1e3, 2),
                          "algorithmic_bytes": by, "algorithmic_flop": fl})
         in_step = [n for n in work if n in kern or n == "prep"]
         step_bytes = sum(work[n][0] for n in in_step)
