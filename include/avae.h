@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AVAE_ABI_VERSION 1
+#define AVAE_ABI_VERSION 2
 #define AVAE_MAX_MODALITIES 4
 #define AVAE_MAX_HIDDEN 8
 
@@ -52,7 +52,10 @@ typedef struct avae_modality {
     int32_t n_hidden[AVAE_MAX_HIDDEN];  /* encoder widths; the MLP decoder reuses them (vae_assoc.py:257,280,293) */
     int32_t binary;                     /* 1: Bernoulli recon + sigmoid output (:321-324,:293-297); 0: Gaussian (:327-328,:299-303) */
     float weight;                       /* reference `weights[m]` (:319,:340) */
-    int32_t hidden_conv;                /* must be 0 (MLP branch); conv/deconv branch is a later round */
+    int32_t hidden_conv;                /* 1: conv encoder / deconv decoder branch (vae_assoc.py:169-210,249-291; deconv.py).
+                                           Needs binary=1 and n_input=784 (the branch is hard-wired to 28x28 images);
+                                           n_hidden[0..1] = n_hidden_recog_1/2 (conv depths), conv_gener = n_hidden_gener_1/2 */
+    int32_t conv_gener[2];
     int32_t reserved;
 } avae_modality;
 

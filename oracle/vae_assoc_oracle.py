@@ -19,6 +19,9 @@ What follows which reference lines (all paths relative to /root/reference):
   Adam                     vae_assoc.py:373-374  (tf.train.AdamOptimizer defaults, TF-1 update rule)
   method semantics         vae_assoc.py:378-425
   train loop               vae_assoc.py:498-583
+  conv encoder branch      vae_assoc.py:169-183, 190-199, 206-210, 480-489 (bias-less convs, NO activation)
+  deconv decoder branch    vae_assoc.py:249-255, 262-278, 286-291, 491-496; deconv.py:76-128, 133-161
+                           (conv2d_transpose + bias + sigmoid on every layer, then a dense n_input x n_input + sigmoid)
 TensorFlow semantics that are not visible in the reference source (marked [TF]) are from
 knowledge of TF 1.x: tf.nn.l2_loss = sum(t**2)/2; Adam adds epsilon to sqrt(v), with
 lr_t = lr*sqrt(1-b2^t)/(1-b1^t); softplus = log(1+exp(x)).
@@ -28,6 +31,13 @@ reference's variable-creation order, per modality:
   enc W1[n_in,H1] b1[H1] W2[H1,H2] b2[H2] ... Wmu[HL,n_z] bmu[n_z] Wsig[HL,n_z] bsig[n_z]
   dec V1[n_z,H1]  c1[H1] V2[H1,H2] c2[H2] ... Vout[HL,n_in] cout[n_in]
 each matrix row-major [fan_in, fan_out] (vae_assoc.py:185-215, 257-300).
+For a modality with hidden_conv=True (binary modalities only; the non-binary conv decoder of the
+reference is shape-broken, vae_assoc.py:299) the order is the creation order of that branch:
+  enc C1[5,5,1,R1] C2[5,5,R1,2R1] C3[5,5,2R1,R2] Wmu[9R2,n_z] bmu Wsig[9R2,n_z] bsig
+  dec T1.W[3,3,G1,n_z] T1.b[G1] T2.W[5,5,G1/2,G1] T2.b T3.W[5,5,G2,G1/2] T3.b T4.W[5,5,1,G2] T4.b
+      Wout[n_in,n_in] bout[n_in]
+(conv filters [k,k,in,out] as tf.nn.conv2d takes them, vae_assoc.py:482; transposed-conv filters
+[k,k,out_depth,in_depth], deconv.py:78).
 """
 from itertools import combinations
 
@@ -36,6 +46,116 @@ import numpy as np
 ADAM_BETA1 = 0.9      # [TF] tf.train.AdamOptimizer defaults
 ADAM_BETA2 = 0.999
 ADAM_EPS = 1e-8
+
+
+# ----------------------------------------------------------------------------- conv primitives (NHWC)
+def _same_pad_before(in_size, k, s):
+    """[TF] SAME padding: out = ceil(in/s), total pad = max((out-1)*s + k - in, 0), the SMALLER half
+    goes before.  For k=5, s=2 on 28 or 14 pixels: 1 before / 2 after, i.e. out[o] = sum_k in[2o+k-1] W[k]."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + k - in_size, 0)
+    return out, total // 2
+
+
+def conv2d(x, W, s, padding):
+    """tf.nn.conv2d(x, W, strides=(1,s,s,1), padding) (vae_assoc.py:484-486); x [B,H,W,Ci], W [k,k,Ci,Co]."""
+    B, H, Wd, Ci = x.shape
+    k = W.shape[0]
+    if padding == "SAME":
+        OH, pb = _same_pad_before(H, k, s)
+        OW, _ = _same_pad_before(Wd, k, s)
+    else:
+        OH, OW, pb = (H - k) // s + 1, (Wd - k) // s + 1, 0
+    xp = np.zeros((B, (OH - 1) * s + k, (OW - 1) * s + k, Ci), dtype=x.dtype)
+    hh, ww = min(H, xp.shape[1] - pb), min(Wd, xp.shape[2] - pb)
+    xp[:, pb:pb + hh, pb:pb + ww] = x[:, :hh, :ww]
+    y = np.zeros((B, OH, OW, W.shape[3]), dtype=np.result_type(x, W))
+    for kh in range(k):
+        for kw in range(k):
+            y += xp[:, kh:kh + (OH - 1) * s + 1:s, kw:kw + (OW - 1) * s + 1:s] @ W[kh, kw]
+    return y
+
+
+def conv2d_bwd(x, W, s, padding, dy):
+    """Gradients of conv2d w.r.t. its input and filter."""
+    B, H, Wd, Ci = x.shape
+    k = W.shape[0]
+    OH, OW = dy.shape[1], dy.shape[2]
+    pb = _same_pad_before(H, k, s)[1] if padding == "SAME" else 0
+    PH, PW = (OH - 1) * s + k, (OW - 1) * s + k
+    xp = np.zeros((B, PH, PW, Ci), dtype=x.dtype)
+    hh, ww = min(H, PH - pb), min(Wd, PW - pb)
+    xp[:, pb:pb + hh, pb:pb + ww] = x[:, :hh, :ww]
+    dxp = np.zeros((B, PH, PW, Ci), dtype=dy.dtype)
+    dW = np.zeros(W.shape, dtype=dy.dtype)
+    for kh in range(k):
+        for kw in range(k):
+            sl = (slice(None), slice(kh, kh + (OH - 1) * s + 1, s), slice(kw, kw + (OW - 1) * s + 1, s))
+            dxp[sl] += dy @ W[kh, kw].T
+            dW[kh, kw] = np.tensordot(xp[sl], dy, axes=([0, 1, 2], [0, 1, 2]))
+    dx = np.zeros(x.shape, dtype=dy.dtype)
+    dx[:, :hh, :ww] = dxp[:, pb:pb + hh, pb:pb + ww]
+    return dx, dW
+
+
+def deconv_out_size(in_size, k, s, padding):
+    """deconv.py:133-161 get2d_deconv_output_size: VALID (in-1)*s+k, SAME in*s."""
+    return (in_size - 1) * s + k if padding == "VALID" else in_size * s
+
+
+def deconv2d(x, W, s, padding):
+    """tf.nn.conv2d_transpose(x, W, output_shape, (1,s,s,1), padding) (deconv.py:107); W [k,k,Co,Ci].
+    [TF] It is the adjoint of the conv2d that maps the OUTPUT image to x: out[i*s + kh - pb] += x[i] W[kh]
+    with pb that conv's pad-before (0 for VALID, 1 for k=5,s=2 SAME): the full transposed conv cropped pb
+    before -- not what torch's conv_transpose2d(padding=2, output_padding=1) does."""
+    B, H, Wd, Ci = x.shape
+    k, Co = W.shape[0], W.shape[2]
+    OH, OW = deconv_out_size(H, k, s, padding), deconv_out_size(Wd, k, s, padding)
+    pb = _same_pad_before(OH, k, s)[1] if padding == "SAME" else 0
+    full = np.zeros((B, (H - 1) * s + k, (Wd - 1) * s + k, Co), dtype=np.result_type(x, W))
+    for kh in range(k):
+        for kw in range(k):
+            full[:, kh:kh + (H - 1) * s + 1:s, kw:kw + (Wd - 1) * s + 1:s] += x @ W[kh, kw].T
+    y = np.zeros((B, OH, OW, Co), dtype=full.dtype)
+    hh, ww = min(OH, full.shape[1] - pb), min(OW, full.shape[2] - pb)
+    y[:, :hh, :ww] = full[:, pb:pb + hh, pb:pb + ww]
+    return y
+
+
+def deconv2d_bwd(x, W, s, padding, dy):
+    """Gradients of deconv2d w.r.t. its input (a plain conv of dy) and its filter."""
+    B, H, Wd, Ci = x.shape
+    k = W.shape[0]
+    OH, OW = dy.shape[1], dy.shape[2]
+    pb = _same_pad_before(OH, k, s)[1] if padding == "SAME" else 0
+    full = np.zeros((B, (H - 1) * s + k, (Wd - 1) * s + k, dy.shape[3]), dtype=dy.dtype)
+    hh, ww = min(OH, full.shape[1] - pb), min(OW, full.shape[2] - pb)
+    full[:, pb:pb + hh, pb:pb + ww] = dy[:, :hh, :ww]
+    dx = np.zeros(x.shape, dtype=dy.dtype)
+    dW = np.zeros(W.shape, dtype=dy.dtype)
+    for kh in range(k):
+        for kw in range(k):
+            g = full[:, kh:kh + (H - 1) * s + 1:s, kw:kw + (Wd - 1) * s + 1:s]      # [B,H,W,Co]
+            dx += g @ W[kh, kw]
+            dW[kh, kw] = np.tensordot(g, x, axes=([0, 1, 2], [0, 1, 2]))
+    return dx, dW
+
+
+def conv_geometry(na):
+    """Layer list of the conv/deconv branch for one modality (vae_assoc.py:169-199, 249-278)."""
+    S = int(round(np.sqrt(na["n_input"])))
+    assert S * S == int(na["n_input"]), "hidden_conv needs a square image"
+    R1, R2 = int(na["n_hidden_recog_1"]), int(na["n_hidden_recog_2"])
+    G1, G2 = int(na["n_hidden_gener_1"]), int(na["n_hidden_gener_2"])
+    enc = [dict(k=5, s=2, pad="SAME", ci=1, co=R1), dict(k=5, s=2, pad="SAME", ci=R1, co=2 * R1),
+           dict(k=5, s=1, pad="VALID", ci=2 * R1, co=R2)]
+    size = S
+    for L in enc:
+        size = _same_pad_before(size, L["k"], L["s"])[0] if L["pad"] == "SAME" else (size - L["k"]) // L["s"] + 1
+    flat = size * size * R2                        # vae_assoc.py:192,198-199 (py2 integer division: 28 -> 7 -> 3)
+    dec = [dict(k=3, s=1, pad="VALID", ci=int(na["n_z"]), co=G1), dict(k=5, s=1, pad="VALID", ci=G1, co=G1 // 2),
+           dict(k=5, s=2, pad="SAME", ci=G1 // 2, co=G2), dict(k=5, s=2, pad="SAME", ci=G2, co=1)]
+    return S, enc, flat, dec
 
 
 # ----------------------------------------------------------------------------- architecture
@@ -51,6 +171,15 @@ def hidden_sizes(na):
 
 def layer_shapes(na):
     """[(name, (fan_in, fan_out))...] for one modality in flat-layout order (W then b)."""
+    if na.get("hidden_conv"):
+        S, enc, flat, dec = conv_geometry(na)
+        n_in, n_z = int(na["n_input"]), int(na["n_z"])
+        shapes = [("enc_C%d" % (i + 1), (L["k"], L["k"], L["ci"], L["co"])) for i, L in enumerate(enc)]
+        shapes += [("enc_Wmu", (flat, n_z)), ("enc_bmu", (n_z,)), ("enc_Wsig", (flat, n_z)), ("enc_bsig", (n_z,))]
+        for i, L in enumerate(dec):
+            shapes += [("dec_T%d_W" % (i + 1), (L["k"], L["k"], L["co"], L["ci"])), ("dec_T%d_b" % (i + 1), (L["co"],))]
+        shapes += [("dec_Wout", (n_in, n_in)), ("dec_bout", (n_in,))]
+        return shapes
     hs = hidden_sizes(na)
     n_in, n_z = int(na["n_input"]), int(na["n_z"])
     shapes = []
@@ -92,6 +221,18 @@ def init_params(archs, rng, dtype=np.float64):
         for name, shp in layer_shapes(na):
             if len(shp) == 2:
                 p[name] = xavier_init(shp[0], shp[1], rng).astype(dtype)
+            elif len(shp) == 4 and name.startswith("enc_C"):
+                # weight_variable (vae_assoc.py:471-473): truncated_normal(stddev=0.1) [TF: redraw beyond 2 sigma]
+                w = rng.standard_normal(shp)
+                while np.any(np.abs(w) > 2):
+                    bad = np.abs(w) > 2
+                    w[bad] = rng.standard_normal(int(bad.sum()))
+                p[name] = (0.1 * w).astype(dtype)
+            elif len(shp) == 4:
+                # deconv.py:83-84 xavier_init(out_depth*k*k, in_depth*k*k) [prettytensor: uniform +-sqrt(6/(a+b))]
+                kk = shp[0] * shp[1]
+                lim = np.sqrt(6.0 / (shp[2] * kk + shp[3] * kk))
+                p[name] = rng.uniform(-lim, lim, size=shp).astype(dtype)
             else:
                 p[name] = np.zeros(shp, dtype=dtype)
         params.append(p)
@@ -193,6 +334,18 @@ def encode(na, p, x, act, quant=None):
     """_recognition_network, MLP branch (vae_assoc.py:185-188,201-204,212-221)."""
     f, _ = ACT[act]
     q = _q(quant)
+    if na.get("hidden_conv"):
+        # vae_assoc.py:169-183,190-199: three bias-less convs with NO activation, flatten (h,w,c), two dense heads
+        S, enc, flat, _dec = conv_geometry(na)
+        h = q(x).reshape(-1, S, S, 1)
+        acts = [h]
+        for i, L in enumerate(enc):
+            h = q(conv2d(h, q(p["enc_C%d" % (i + 1)]), L["s"], L["pad"]))
+            acts.append(h)
+        hf = h.reshape(h.shape[0], flat)
+        mu = hf @ q(p["enc_Wmu"]) + q(p["enc_bmu"])
+        lv = hf @ q(p["enc_Wsig"]) + q(p["enc_bsig"])
+        return mu, lv, {"acts": acts, "conv": True}
     hs = hidden_sizes(na)
     h = q(x)
     acts, pre = [h], []
@@ -210,6 +363,19 @@ def decode(na, p, z, act, binary, quant=None):
     """_generator_network, MLP branch (vae_assoc.py:257-260,280-283,293-303)."""
     f, _ = ACT[act]
     q = _q(quant)
+    if na.get("hidden_conv"):
+        # vae_assoc.py:249-278,286-291: four conv2d_transpose layers, each + bias + SIGMOID (deconv_2d's default
+        # transfer_fct, :491, is never overridden), flatten, dense n_input x n_input + sigmoid
+        assert binary, "the reference's non-binary conv decoder is shape-broken (vae_assoc.py:299)"
+        S, _enc, _flat, dec = conv_geometry(na)
+        g = q(z).reshape(-1, 1, 1, int(na["n_z"]))
+        acts = [g]
+        for i, L in enumerate(dec):
+            g = q(_sigmoid(deconv2d(g, q(p["dec_T%d_W" % (i + 1)]), L["s"], L["pad"]) + q(p["dec_T%d_b" % (i + 1)])))
+            acts.append(g)
+        gf = g.reshape(g.shape[0], -1)
+        logits = gf @ q(p["dec_Wout"]) + q(p["dec_bout"])
+        return _sigmoid(logits), {"acts": acts, "logits": logits, "conv": True}
     hs = hidden_sizes(na)
     g = q(z)
     acts, pre = [g], []
@@ -317,6 +483,9 @@ def backward(archs, params, fw, X, eps, binary, weights, assoc_lambda, act, batc
         dlv[j] = dlv[j] + 0.5 * assoc_lambda * (np.exp(-a) - np.exp(a) - d ** 2 * np.exp(-lj))
     grads = []
     for m, (na, p, f, x, b, w) in enumerate(zip(archs, params, fw, X, binary, weights)):
+        if na.get("hidden_conv"):
+            grads.append(_backward_conv(na, p, f, x, eps, w, Bg, dmu[m], dlv[m], q))
+            continue
         hs = hidden_sizes(na)
         L = len(hs)
         g = {}
@@ -353,6 +522,40 @@ def backward(archs, params, fw, X, eps, binary, weights, assoc_lambda, act, batc
                 dh = da @ q(p["enc_W%d" % (i + 1)]).T
         grads.append(g)
     return grads, {"dmu_direct": dmu, "dlv_direct": dlv}
+
+
+def _backward_conv(na, p, f, x, eps, w, Bg, dmu_direct, dlv_direct, q):
+    """Backward pass of the conv/deconv branch (binary modality)."""
+    S, enc, flat, dec = conv_geometry(na)
+    g = {}
+    xr = f["xhat"]
+    dl = q((w / Bg) * xr * (1 - xr) * (-x / (1e-3 + xr) + (1 - x) / (1e-3 + 1 - xr)))
+    dacts = f["dec"]["acts"]
+    gf = dacts[-1].reshape(dacts[-1].shape[0], -1)
+    g["dec_Wout"] = gf.T @ dl
+    g["dec_bout"] = dl.sum(0)
+    dy = (dl @ q(p["dec_Wout"]).T).reshape(dacts[-1].shape)
+    for i in range(len(dec) - 1, -1, -1):
+        y = dacts[i + 1]
+        da = q(dy * y * (1.0 - y))                                   # sigmoid' from the stored output
+        dy, dW = deconv2d_bwd(dacts[i], q(p["dec_T%d_W" % (i + 1)]), dec[i]["s"], dec[i]["pad"], da)
+        g["dec_T%d_W" % (i + 1)] = dW
+        g["dec_T%d_b" % (i + 1)] = da.sum((0, 1, 2))
+    dz = dy.reshape(dy.shape[0], -1)
+    gmu = q(dmu_direct + dz)
+    glv = q(dlv_direct + dz * 0.5 * np.sqrt(np.exp(f["lv"])) * eps)
+    eacts = f["enc"]["acts"]
+    hf = eacts[-1].reshape(eacts[-1].shape[0], flat)
+    g["enc_Wmu"] = hf.T @ gmu
+    g["enc_bmu"] = gmu.sum(0)
+    g["enc_Wsig"] = hf.T @ glv
+    g["enc_bsig"] = glv.sum(0)
+    dh = q((gmu @ q(p["enc_Wmu"]).T + glv @ q(p["enc_Wsig"]).T).reshape(eacts[-1].shape))   # convs carry no activation
+    for i in range(len(enc) - 1, -1, -1):
+        dx, dW = conv2d_bwd(eacts[i], q(p["enc_C%d" % (i + 1)]), enc[i]["s"], enc[i]["pad"], dh)
+        g["enc_C%d" % (i + 1)] = dW
+        dh = q(dx)
+    return g
 
 
 # ----------------------------------------------------------------------------- Adam

@@ -212,6 +212,32 @@ def test_shapes_and_options(V, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv_deconv_branch(V, dtype):
+    """hidden_conv=True image modality (vae_assoc.py:169-210,249-291; deconv.py) paired with the MLP joint
+    modality: the commented-out configuration of vae_assoc_ujichar_img_jnt.py:72-80 (depths 16/64, 64/16)."""
+    img = dict(make_arch("image", 784, 16, 64, 20), hidden_conv=True, n_hidden_gener_1=64, n_hidden_gener_2=16)
+    jnt = make_arch("joint", 147, 200, 200, 20)
+    model, emu, X, eps = check_step_parity(V, [img, jnt], [True, False], [50.0, 1.0], 8.0, "relu", 24, dtype, steps=2)
+    # inference surface of the conv modality, any row count
+    rng = np.random.default_rng(9)
+    for rows in (1, 24, 31):
+        Xr = synth_batch(rng, rows, [784, 147], [True, False])
+        z = rng.standard_normal((rows, 20)).astype(np.float32)
+        e = [rng.standard_normal((rows, 20)).astype(np.float32) for _ in range(2)]
+        tol = 2e-5 if dtype == "fp32" else 3e-3
+        assert np.abs(model.transform(Xr)[0] - emu.transform(Xr)[0]).max() <= tol * 5
+        assert np.abs(model.generate(z)[0] - emu.generate(z)[0]).max() <= tol
+        assert np.abs(model.reconstruct(Xr, eps=e)[0] - emu.reconstruct(Xr, eps=e)[0]).max() <= tol
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv_only_model(V, dtype):
+    """A single conv modality (no MLP modality at all, no association term)."""
+    img = dict(make_arch("image", 784, 8, 12, 6), hidden_conv=True, n_hidden_gener_1=12, n_hidden_gener_2=6)
+    check_step_parity(V, [img], True, 1.0, 1.0, "relu", 10, dtype, steps=2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_large_tile_path(V, dtype):
     """Wide layers and a large batch select the 128x128 tile configuration.  softplus, not relu:
     with 2048 x 384 hidden units some pre-activation lands within fp32 rounding of the relu kink and
@@ -300,8 +326,10 @@ def test_wrong_shapes_raise(V):
         model.partial_fit([np.zeros((15, 784), np.float32), np.zeros((15, 147), np.float32)])
     with pytest.raises(ValueError):
         model.transform(np.zeros((4, 100), np.float32), sens_idx=0)
-    with pytest.raises(NotImplementedError):
-        V.AssocVariationalAutoEncoder([dict(archs[0], hidden_conv=True)], batch_size=4)
+    with pytest.raises(ValueError):          # the conv branch is hard-wired to 28x28 / binary
+        V.AssocVariationalAutoEncoder([dict(make_arch("x", 100, 4, 4, 20), hidden_conv=True)], batch_size=4)
+    with pytest.raises(ValueError):
+        V.AssocVariationalAutoEncoder([dict(archs[0], hidden_conv=True)], binary=False, batch_size=4)
     with pytest.raises(ValueError):
         V.AssocVariationalAutoEncoder([archs[0], dict(archs[1], n_z=7)], batch_size=4)
 

@@ -87,6 +87,64 @@ def test_oracle_matches_torch_autograd(case):
     assert np.abs(g - tg).max() <= 1e-9 * max(1.0, np.abs(tg).max())
 
 
+def test_conv_primitives_match_torch():
+    """conv2d / conv2d_transpose restatements (incl. TF SAME alignment: pad 1 before / 2 after for k=5, s=2;
+    the transposed conv is the full one cropped 1 before) against torch, forward and both gradients."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    for (H, ci, co, k, s, pad) in [(28, 1, 4, 5, 2, "SAME"), (14, 4, 8, 5, 2, "SAME"), (7, 8, 6, 5, 1, "VALID")]:
+        x, W = rng.standard_normal((3, H, H, ci)), rng.standard_normal((k, k, ci, co))
+        y = O.conv2d(x, W, s, pad)
+        xt, Wt = torch.tensor(x, requires_grad=True), torch.tensor(W, requires_grad=True)
+        xp = xt.permute(0, 3, 1, 2)
+        xp = F.pad(xp, (1, 2, 1, 2)) if pad == "SAME" else xp
+        yt = F.conv2d(xp, Wt.permute(3, 2, 0, 1), stride=s).permute(0, 2, 3, 1)
+        assert np.abs(y - yt.detach().numpy()).max() < 1e-12
+        dy = rng.standard_normal(y.shape)
+        (yt * torch.tensor(dy)).sum().backward()
+        dx, dW = O.conv2d_bwd(x, W, s, pad, dy)
+        assert np.abs(dx - xt.grad.numpy()).max() < 1e-12 and np.abs(dW - Wt.grad.numpy()).max() < 1e-11
+    for (H, ci, co, k, s, pad) in [(1, 5, 6, 3, 1, "VALID"), (3, 6, 3, 5, 1, "VALID"), (7, 3, 4, 5, 2, "SAME"), (14, 4, 1, 5, 2, "SAME")]:
+        x, W = rng.standard_normal((2, H, H, ci)), rng.standard_normal((k, k, co, ci))
+        y = O.deconv2d(x, W, s, pad)
+        assert y.shape[1] == O.deconv_out_size(H, k, s, pad)
+        xt, Wt = torch.tensor(x, requires_grad=True), torch.tensor(W, requires_grad=True)
+        pb, OH = (1 if pad == "SAME" else 0), y.shape[1]
+        yt = F.conv_transpose2d(xt.permute(0, 3, 1, 2), Wt.permute(3, 2, 0, 1), stride=s).permute(0, 2, 3, 1)[:, pb:pb + OH, pb:pb + OH]
+        assert np.abs(y - yt.detach().numpy()).max() < 1e-12
+        u = rng.standard_normal(y.shape)          # adjoint of the conv that maps the output image back to x
+        assert abs((y * u).sum() - (x * O.conv2d(u, W, s, pad)).sum()) < 1e-10
+        dy = rng.standard_normal(y.shape)
+        (yt * torch.tensor(dy)).sum().backward()
+        dx, dW = O.deconv2d_bwd(x, W, s, pad, dy)
+        assert np.abs(dx - xt.grad.numpy()).max() < 1e-12 and np.abs(dW - Wt.grad.numpy()).max() < 1e-11
+
+
+def test_conv_branch_gradients_by_finite_differences():
+    img = dict(make_arch("image", 784, 4, 6, 5), hidden_conv=True, n_hidden_gener_1=8, n_hidden_gener_2=4)
+    jnt = make_arch("joint", 21, 12, 10, 5)
+    archs = [img, jnt]
+    assert [n for n, _ in O.layer_shapes(img)][:3] == ["enc_C1", "enc_C2", "enc_C3"]
+    rng = np.random.default_rng(3)
+    X = [rng.random((3, 784)), rng.standard_normal((3, 21))]
+    eps = rng.standard_normal((3, 5))
+    m = O.OracleAssocVAE(archs, [True, False], "relu", [2.0, 1.0], 0.5, 1e-3, 3, seed=1)
+    th = m.get_params() + 0.02 * rng.standard_normal(O.param_count(archs))
+    m.set_params(th)
+    _, g, _ = m.cost_and_grads(X, eps)
+    off, picks = 0, []
+    for name, shp in O.layer_shapes(img):          # a few entries of every tensor of the conv modality
+        n = int(np.prod(shp))
+        picks += list(off + rng.integers(0, n, 3))
+        off += n
+    for i in picks:
+        h = 1e-6
+        t2 = th.copy(); t2[i] += h; m.set_params(t2); cp = m.evaluate_cost(X, eps)
+        t2[i] -= 2 * h; m.set_params(t2); cm = m.evaluate_cost(X, eps)
+        fd = (cp - cm) / (2 * h)
+        assert abs(fd - g[i]) <= 2e-5 * max(1.0, abs(g[i])), (i, fd, g[i])
+
+
 def test_oracle_finite_differences():
     case = CASES[1]
     rng = np.random.default_rng(2)

@@ -12,7 +12,7 @@ import threading
 
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
-AVAE_ABI_VERSION = 1
+AVAE_ABI_VERSION = 2
 AVAE_MAX_MODALITIES = 4
 AVAE_MAX_HIDDEN = 8
 
@@ -35,7 +35,8 @@ SYMBOLS = [
 class Modality(C.Structure):
     _fields_ = [("n_input", C.c_int32), ("n_hidden_layers", C.c_int32),
                 ("n_hidden", C.c_int32 * AVAE_MAX_HIDDEN), ("binary", C.c_int32),
-                ("weight", C.c_float), ("hidden_conv", C.c_int32), ("reserved", C.c_int32)]
+                ("weight", C.c_float), ("hidden_conv", C.c_int32), ("conv_gener", C.c_int32 * 2),
+                ("reserved", C.c_int32)]
 
 
 class Config(C.Structure):

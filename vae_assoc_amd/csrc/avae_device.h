@@ -26,6 +26,7 @@ enum Kind : int {
     K_DGRAD_LATENT = 5,  // dz = dA . V1^T; dmu, dlv via reparam + static latent grads -> dH, dH^T
     K_WGRAD = 6,         // dW_aug = X_aug^T . dA (bias grad = last row) -> fp32 gradient
     K_WGRAD_ADAM = 9,    // the same product with the TF-1 Adam update + shadow refresh fused into its epilogue
+    K_DGRAD_F32 = 10,    // dP = dA . W^T stored as fp32 (conv branch: patch gradients, summed by k_col2im)
     K_LATENT = 7,        // KL(q||N(0,I)) + association penalty: cost partials + static (mu,lv) grads (:335-366)
     K_COST = 8,          // fixed-order sum of the cost partials -> grad[cost slot]; bumps the step counter
 };
@@ -129,6 +130,42 @@ struct PrepArgs {
     const DevState* st;
     unsigned long long stream_salt;   // distinguishes train / eval / reconstruct draws
 };
+
+// Conv / transposed-conv layers (reference vae_assoc.py:169-199,249-278, deconv.py:107) run on the
+// same GEMM kernel through explicit patch matrices.  One geometry covers both directions:
+//   P[(b,oh,ow)][(kh,kw,ci)] = X[b, (oh*so + kh - pad)/d, (ow*so + kw - pad)/d, ci]   (0 if not divisible / out of range)
+// conv: so = stride, d = 1, pad = TF pad-before;  transposed conv: so = 1, d = stride, pad = k-1-pad_before with
+// the filter flipped when it is laid out as a matrix;  flatten+dense: k = map size, VALID.
+struct ConvGeom {
+    int B, IH, IW, Cin, OH, OW, k, so, d, pad;
+    int src_sb, src_sp;        // element strides of the source: batch, pixel (channel stride 1)
+    int ones;                  // append the constant-1 bias column at index k*k*Cin
+};
+// k_gather (im2col): source activations -> patch matrix P (row-major + transposed), compute dtype
+struct GatherSeg {
+    ConvGeom g;
+    const void* src;
+    void* P; int ldp;
+    void* Pt; int ldpt;        // nullable
+    int tiles_r, tiles_c, tile_base;
+};
+struct GatherArgs { GatherSeg seg[kMaxMod]; int n_seg; };
+// k_col2im: fp32 patch gradients dP -> gradient of the layer input, times act'(stored input), written
+// row-major + transposed in the compute dtype; latent mode turns dz into [dmu | dlv] (reparameterisation).
+struct Col2imSeg {
+    ConvGeom g;
+    const float* dP; int lddp;
+    const void* yprev; int ldy;      // stored output of the producing layer (nullable -> identity)
+    int act;                          // AVAE_ACT_* of the producing layer
+    void* dA; int lda;                // [B*IH*IW][lda]
+    void* dAt; int ldat;              // [Cin (or 2*nz)][ldat]
+    const float* g0; int nz;          // latent mode when g0 != nullptr
+    int tiles_r, tiles_c, tile_base;
+};
+struct Col2imArgs { Col2imSeg seg[kMaxMod]; int n_seg; };
+
+void launch_gather(int compute_dtype, const GatherArgs& a, int n_blocks, hipStream_t s);
+void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStream_t s);
 
 // Diagnostic build only (-DAVAE_STAMPS): thread 0 of every block records s_memrealtime (100 MHz)
 // at kernel entry / after the item lookup / after the first staged tile / after the K loop / at

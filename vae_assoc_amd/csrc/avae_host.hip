@@ -48,11 +48,27 @@ struct Dense {             // one dense layer, weights + bias as W_aug [(in+1)][
     bool head = false;     // [mu|sigma] fused head: flat layout is Wmu,bmu,Wsig,bsig
 };
 
-struct Act {               // activation or gradient: row-major [Bp][ld] + transposed [rup(width+1,128)][ldT]
+struct Act {               // activation or gradient: row-major [rows p][ld] + transposed [rup(width+1,128)][ldT]
     int width = 0;
+    int rows = 0;          // logical rows (batch, or batch * output pixels for a conv stage)
     int ld = 0, ldT = 0;
     size_t rm = 0, tr = 0;
     bool ones = false;
+};
+
+// One conv-like stage of the conv/deconv branch: gather (im2col) -> GEMM on the patch matrix.
+struct ConvStage {
+    ConvGeom g{};          // for the training batch
+    Dense d;               // in = k*k*Cin, out = Cout (W_aug: bias row only fed when `bias`)
+    bool bias = false;
+    int act = AVAE_ACT_IDENTITY;   // transfer function applied to this stage's output
+    int flat = 0;          // flat-parameter form: 0 conv filter [k,k,ci,co] (no bias); 1 transposed-conv filter
+                           // [k,k,co,ci] + bias[co]; 2 dense W[in,out] + b; 3 fused head Wmu,bmu,Wsig,bsig
+    Act P;                 // patch matrix, rows = B*OH*OW, width = k*k*Cin
+    Act Y;                 // stage output (row-major only), NHWC rows
+    Act dY;                // gradient w.r.t. the stage's pre-activation output (row-major + transposed)
+    size_t dP = 0;         // fp32 patch gradients [rows][lddp]
+    int lddp = 0;
 };
 
 struct Mod {
@@ -64,12 +80,17 @@ struct Mod {
     std::vector<Act> E, D, dE, dD;
     size_t X32 = 0, mulv = 0, g0 = 0, out32 = 0;
     int ld32 = 0;
+    bool conv = false;             // hidden_conv branch: cenc = E1,E2,E3,HEAD  cdec = T1,T2,T3,T4,OUT
+    std::vector<ConvStage> cenc, cdec;
 };
 
 struct Launch {
     std::string name;
+    int type = 0;          // 0: grouped GEMM kernel, 1: k_gather (im2col), 2: k_col2im
     int cfg = 0, first = 0, count = 0, blocks = 0, lds = 0;
     LaunchArgs args{};
+    GatherArgs ga{};
+    Col2imArgs ca{};
 };
 
 struct TimingRec { hipEvent_t a, b; int launch_name; };
@@ -117,14 +138,15 @@ struct avae_handle {
 
 namespace {
 
-Act make_act(Bump& b, int width, bool ones, int Bp, int ldB, int KU, int es) {
+Act make_act(Bump& b, int width, bool ones, int rows, int KU, int es, bool want_rm = true, bool want_tr = true) {
     Act a;
     a.width = width;
+    a.rows = rows;
     a.ones = ones;
     a.ld = (int)rup(width + 1, KU);
-    a.ldT = ldB;
-    a.rm = b.take((size_t)Bp * a.ld * es);
-    a.tr = b.take(rup(width + 1, kRowAlign) * (size_t)a.ldT * es);
+    a.ldT = (int)rup(rows, KU);
+    if (want_rm) a.rm = b.take(rup(rows, kRowAlign) * (size_t)a.ld * es);
+    if (want_tr) a.tr = b.take(rup(width + 1, kRowAlign) * (size_t)a.ldT * es);
     return a;
 }
 
@@ -149,8 +171,14 @@ void check_config(const avae_config& c) {
     if (c.activation < AVAE_ACT_IDENTITY || c.activation > AVAE_ACT_TANH) throw Err("unknown activation");
     for (int m = 0; m < c.n_modalities; ++m) {
         const avae_modality& mo = c.mod[m];
-        if (mo.hidden_conv) throw Err("hidden_conv=1 (conv/deconv branch) is not built yet; only the MLP branch");
         if (mo.n_input < 1) throw Err("n_input must be positive");
+        if (mo.hidden_conv) {
+            // the reference's branch is hard-wired to 28x28: 28 -> 14 -> 7 -> 3 in the encoder (vae_assoc.py:171-199),
+            // 1 -> 3 -> 7 -> 14 -> 28 in the decoder (:250-278) and a dense n_input x n_input on top (:287)
+            if (mo.n_input != 784) throw Err("hidden_conv needs n_input = 784 (28x28 images)");
+            if (!mo.binary) throw Err("hidden_conv needs a binary modality (the reference's non-binary conv decoder is shape-broken, vae_assoc.py:299)");
+            if (mo.n_hidden_layers != 2 || mo.conv_gener[0] < 2 || mo.conv_gener[1] < 1) throw Err("hidden_conv needs n_hidden_recog_1/2 and n_hidden_gener_1 (>=2) / n_hidden_gener_2");
+        }
         if (mo.n_hidden_layers < 1 || mo.n_hidden_layers > AVAE_MAX_HIDDEN) throw Err("n_hidden_layers out of range");
         for (int k = 0; k < mo.n_hidden_layers; ++k)
             if (mo.n_hidden[k] < 1) throw Err("hidden width must be positive");
@@ -178,23 +206,67 @@ void plan_memory(avae_handle* h) {
         md.n_in = mo.n_input;
         md.L = mo.n_hidden_layers;
         md.hs.assign(mo.n_hidden, mo.n_hidden + md.L);
-        int prev = md.n_in;
-        for (int k = 0; k < md.L; ++k) { md.enc.push_back(make_dense(b, pint, prev, md.hs[k], KU, es, false)); pflat += (size_t)(prev + 1) * md.hs[k]; prev = md.hs[k]; }
-        md.head = make_dense(b, pint, prev, 2 * nz, KU, es, true);
-        pflat += (size_t)(prev + 1) * 2 * nz;
-        prev = nz;
-        for (int k = 0; k < md.L; ++k) { md.dec.push_back(make_dense(b, pint, prev, md.hs[k], KU, es, false)); pflat += (size_t)(prev + 1) * md.hs[k]; prev = md.hs[k]; }
-        md.outl = make_dense(b, pint, prev, md.n_in, KU, es, false);
-        pflat += (size_t)(prev + 1) * md.n_in;
-
-        md.X0 = make_act(b, md.n_in, true, Bp, ldB, KU, es);
-        for (int k = 0; k < md.L; ++k) md.E.push_back(make_act(b, md.hs[k], true, Bp, ldB, KU, es));
-        md.Z = make_act(b, nz, true, Bp, ldB, KU, es);
-        for (int k = 0; k < md.L; ++k) md.D.push_back(make_act(b, md.hs[k], true, Bp, ldB, KU, es));
-        for (int k = 0; k < md.L; ++k) md.dE.push_back(make_act(b, md.hs[k], false, Bp, ldB, KU, es));
-        md.dH = make_act(b, 2 * nz, false, Bp, ldB, KU, es);
-        for (int k = 0; k < md.L; ++k) md.dD.push_back(make_act(b, md.hs[k], false, Bp, ldB, KU, es));
-        md.dO = make_act(b, md.n_in, false, Bp, ldB, KU, es);
+        md.conv = mo.hidden_conv != 0;
+        auto act_B = [&](int width, bool ones) { return make_act(b, width, ones, B, KU, es); };
+        if (!md.conv) {
+            int prev = md.n_in;
+            for (int k = 0; k < md.L; ++k) { md.enc.push_back(make_dense(b, pint, prev, md.hs[k], KU, es, false)); pflat += (size_t)(prev + 1) * md.hs[k]; prev = md.hs[k]; }
+            md.head = make_dense(b, pint, prev, 2 * nz, KU, es, true);
+            pflat += (size_t)(prev + 1) * 2 * nz;
+            prev = nz;
+            for (int k = 0; k < md.L; ++k) { md.dec.push_back(make_dense(b, pint, prev, md.hs[k], KU, es, false)); pflat += (size_t)(prev + 1) * md.hs[k]; prev = md.hs[k]; }
+            md.outl = make_dense(b, pint, prev, md.n_in, KU, es, false);
+            pflat += (size_t)(prev + 1) * md.n_in;
+            md.X0 = act_B(md.n_in, true);
+            for (int k = 0; k < md.L; ++k) md.E.push_back(act_B(md.hs[k], true));
+            md.Z = act_B(nz, true);
+            for (int k = 0; k < md.L; ++k) md.D.push_back(act_B(md.hs[k], true));
+            for (int k = 0; k < md.L; ++k) md.dE.push_back(act_B(md.hs[k], false));
+            md.dH = act_B(2 * nz, false);
+            for (int k = 0; k < md.L; ++k) md.dD.push_back(act_B(md.hs[k], false));
+            md.dO = act_B(md.n_in, false);
+        } else {
+            const int R1 = md.hs[0], R2 = md.hs[1], G1 = mo.conv_gener[0], G2 = mo.conv_gener[1];
+            md.L = 0;
+            md.X0 = act_B(md.n_in, false);
+            md.Z = act_B(nz, false);
+            md.dH = act_B(2 * nz, false);
+            md.dO = act_B(md.n_in, false);
+            auto stage = [&](int IH, int Cin, int OH, int Cout, int k, int so, int d, int pad, bool bias, int act, int flat, bool plain_out) {
+                ConvStage st;
+                st.g = ConvGeom{B, IH, IH, Cin, OH, OH, k, so, d, pad, 0, 0, bias ? 1 : 0};
+                st.bias = bias; st.act = act; st.flat = flat;
+                const int K = k * k * Cin, rows = B * OH * OH;
+                st.d = make_dense(b, pint, K, Cout, KU, es, flat == 3);
+                st.P = make_act(b, K, bias, rows, KU, es);
+                if (plain_out) {     // hidden conv stage: own output / gradient buffers
+                    st.Y = make_act(b, Cout, false, rows, KU, es, true, false);
+                    st.dY = make_act(b, Cout, false, rows, KU, es);
+                }
+                st.lddp = (int)rup(K, 8);
+                st.dP = b.take((size_t)rows * st.lddp * 4);
+                pflat += (size_t)K * Cout + (flat == 0 ? 0 : Cout);
+                return st;
+            };
+            // encoder: conv k5 s2 SAME (pad-before 1), conv k5 s2 SAME, conv k5 s1 VALID, flatten(3x3) + dense heads
+            md.cenc.push_back(stage(28, 1, 14, R1, 5, 2, 1, 1, false, AVAE_ACT_IDENTITY, 0, true));
+            md.cenc.push_back(stage(14, R1, 7, 2 * R1, 5, 2, 1, 1, false, AVAE_ACT_IDENTITY, 0, true));
+            md.cenc.push_back(stage(7, 2 * R1, 3, R2, 5, 1, 1, 0, false, AVAE_ACT_IDENTITY, 0, true));
+            md.cenc.push_back(stage(3, R2, 1, 2 * nz, 3, 1, 1, 0, true, AVAE_ACT_IDENTITY, 3, false));
+            // decoder: transposed convs as convs of the dilated input with the flipped filter (pad = k-1-pad_before)
+            md.cdec.push_back(stage(1, nz, 3, G1, 3, 1, 1, 2, true, AVAE_ACT_SIGMOID, 1, true));
+            md.cdec.push_back(stage(3, G1, 7, G1 / 2, 5, 1, 1, 4, true, AVAE_ACT_SIGMOID, 1, true));
+            md.cdec.push_back(stage(7, G1 / 2, 14, G2, 5, 1, 2, 3, true, AVAE_ACT_SIGMOID, 1, true));
+            md.cdec.push_back(stage(14, G2, 28, 1, 5, 1, 2, 3, true, AVAE_ACT_SIGMOID, 1, true));
+            md.cdec.push_back(stage(28, 1, 1, md.n_in, 28, 1, 1, 0, true, AVAE_ACT_IDENTITY, 2, false));
+            md.head = md.cenc[3].d;
+            md.outl = md.cdec[4].d;
+            auto src = [](ConvStage& st, int sb, int sp) { st.g.src_sb = sb; st.g.src_sp = sp; };
+            src(md.cenc[0], md.X0.ld, 1);
+            for (int i = 1; i < 4; ++i) { const ConvStage& pv = md.cenc[i - 1]; src(md.cenc[i], pv.g.OH * pv.g.OW * pv.Y.ld, pv.Y.ld); }
+            src(md.cdec[0], md.Z.ld, 0);
+            for (int i = 1; i < 5; ++i) { const ConvStage& pv = md.cdec[i - 1]; src(md.cdec[i], pv.g.OH * pv.g.OW * pv.Y.ld, pv.Y.ld); }
+        }
         md.ld32 = (int)rup(md.n_in, 8);      // multiple of the widest epilogue vector (8 elements)
         md.X32 = b.take((size_t)B * md.ld32 * 4);
         md.out32 = b.take((size_t)B * md.ld32 * 4);
@@ -221,7 +293,7 @@ void plan_memory(avae_handle* h) {
     n_train_items += 8;
     h->off_items = b.take(n_train_items * sizeof(WorkItem));
     size_t n_adam = 0;
-    for (int m = 0; m < h->M; ++m) n_adam += 2 * (size_t)h->mods[m].L + 2;
+    for (int m = 0; m < h->M; ++m) n_adam += h->mods[m].conv ? 9 : 2 * (size_t)h->mods[m].L + 2;
     h->off_adam = b.take(n_adam * sizeof(AdamItem));
     h->off_inf = b.off;
     for (int m = 0; m < h->M; ++m) b.take(2 * ((size_t)h->mods[m].L + 1) * sizeof(WorkItem));
@@ -250,7 +322,27 @@ void convert_params(const avae_handle* h, float* flat, float* internal) {
             }
         }
     };
+    auto xfer = [&](float& x) { if (ToInternal) x = flat[f]; else flat[f] = x; ++f; };
+    auto conv_stage = [&](const ConvStage& st) {
+        const Dense& d = st.d;
+        float* I = internal + d.master;
+        const int k = st.g.k, Ci = st.g.Cin, Co = d.out, K = k * k * Ci;
+        if (st.flat == 0) {            // tf.nn.conv2d filter [k,k,ci,co] == matrix rows (kh,kw,ci) x cols co; no bias
+            for (int r = 0; r < K; ++r) for (int c = 0; c < Co; ++c) xfer(I[(size_t)r * d.ld + c]);
+        } else if (st.flat == 1) {     // conv2d_transpose filter [k,k,co,ci] (deconv.py:78), flipped into the matrix; bias[co]
+            for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw) for (int co = 0; co < Co; ++co) for (int ci = 0; ci < Ci; ++ci)
+                xfer(I[(size_t)(((k - 1 - kh) * k + (k - 1 - kw)) * Ci + ci) * d.ld + co]);
+            for (int co = 0; co < Co; ++co) xfer(I[(size_t)K * d.ld + co]);
+        } else {
+            dense(d);                  // dense on the flattened map (2) or the fused heads (3: d.head)
+        }
+    };
     for (const Mod& md : h->mods) {
+        if (md.conv) {
+            for (const ConvStage& st : md.cenc) conv_stage(st);
+            for (const ConvStage& st : md.cdec) conv_stage(st);
+            continue;
+        }
         for (const Dense& d : md.enc) dense(d);
         dense(md.head);
         for (const Dense& d : md.dec) dense(d);
@@ -285,7 +377,7 @@ struct Builder {
         return w;
     }
     WorkItem fwd_head(const Mod& md, bool with_z) {
-        const Act& in = md.E.back();
+        const Act& in = md.conv ? md.cenc[3].P : md.E.back();
         WorkItem w = gemm_item(K_FWD_HEAD, B, 2 * h->nz, K_of(md.head.in + 1), p<void>(in.rm), in.ld, p<void>(md.head.Wt), md.head.ldt);
         w.nz = h->nz;
         w.out0 = p<void>(md.mulv); w.ld0 = 2 * h->nz;
@@ -295,7 +387,7 @@ struct Builder {
         return w;
     }
     WorkItem fwd_out(const Mod& md, int m, bool loss) {
-        const Act& in = md.D.back();
+        const Act& in = md.conv ? md.cdec[4].P : md.D.back();
         WorkItem w = gemm_item(loss ? K_FWD_OUT_LOSS : K_FWD_OUT_STORE, B, md.n_in, K_of(md.outl.in + 1), p<void>(in.rm), in.ld,
                                p<void>(md.outl.Wt), md.outl.ldt);
         w.binary = h->cfg.mod[m].binary ? 1 : 0;
@@ -329,8 +421,54 @@ struct Builder {
         w.out1 = p<void>(md.dH.tr); w.ld1 = md.dH.ldT;
         return w;
     }
+    // ---- conv branch: every stage is a GEMM on its patch matrix
+    int conv_rows(const ConvStage& st) const { return B * st.g.OH * st.g.OW; }
+    WorkItem conv_fwd(const ConvStage& st) {
+        WorkItem w = gemm_item(K_FWD_HIDDEN, conv_rows(st), st.d.out, K_of(st.d.in + 1), p<void>(st.P.rm), st.P.ld, p<void>(st.d.Wt), st.d.ldt);
+        w.act = st.act;
+        w.out0 = p<void>(st.Y.rm); w.ld0 = st.Y.ld;
+        return w;
+    }
+    WorkItem conv_dgrad(const ConvStage& st, const Act& dA) {          // fp32 patch gradients dP = dA . W^T
+        WorkItem w = gemm_item(K_DGRAD_F32, conv_rows(st), st.d.in, K_of(st.d.out), p<void>(dA.rm), dA.ld, p<void>(st.d.W), st.d.ld);
+        w.out0 = p<void>(st.dP); w.ld0 = st.lddp;
+        return w;
+    }
+    GatherSeg gather_seg(const ConvStage& st, const void* src, bool with_t) {
+        GatherSeg g;
+        std::memset(&g, 0, sizeof(g));
+        g.g = st.g; g.g.B = B;
+        g.src = src;
+        g.P = p<void>(st.P.rm); g.ldp = st.P.ld;
+        g.Pt = with_t ? p<void>(st.P.tr) : nullptr; g.ldpt = st.P.ldT;
+        const int M = conv_rows(st), KC = st.d.in + (st.bias ? 1 : 0);
+        g.tiles_r = (M + 63) / 64; g.tiles_c = (KC + 63) / 64;
+        return g;
+    }
+    // gradient of stage `st`'s input: into the producing stage `prev` (nullptr: latent mode -> dH of `md`)
+    Col2imSeg col2im_seg(const ConvStage& st, const ConvStage* prev, const Mod& md) {
+        Col2imSeg c;
+        std::memset(&c, 0, sizeof(c));
+        c.g = st.g; c.g.B = B;
+        c.dP = p<float>(st.dP); c.lddp = st.lddp;
+        int C;
+        if (prev) {
+            c.yprev = prev->act == AVAE_ACT_IDENTITY ? nullptr : p<void>(prev->Y.rm); c.ldy = prev->Y.ld; c.act = prev->act;
+            c.dA = p<void>(prev->dY.rm); c.lda = prev->dY.ld;
+            c.dAt = p<void>(prev->dY.tr); c.ldat = prev->dY.ldT;
+            C = st.g.Cin;
+        } else {
+            c.g0 = p<float>(md.g0); c.nz = h->nz;
+            c.dA = p<void>(md.dH.rm); c.lda = md.dH.ld;
+            c.dAt = p<void>(md.dH.tr); c.ldat = md.dH.ldT;
+            C = 2 * h->nz;
+        }
+        const int R = B * st.g.IH * st.g.IW;
+        c.tiles_r = (R + 63) / 64; c.tiles_c = (C + 63) / 64;
+        return c;
+    }
     WorkItem wgrad(const Act& x, const Dense& d, const Act& dA, bool adam = false) {
-        WorkItem w = gemm_item(adam ? K_WGRAD_ADAM : K_WGRAD, d.in + 1, d.out, K_of(B), p<void>(x.tr), x.ldT, p<void>(dA.tr), dA.ldT);
+        WorkItem w = gemm_item(adam ? K_WGRAD_ADAM : K_WGRAD, d.in + 1, d.out, K_of(x.rows), p<void>(x.tr), x.ldT, p<void>(dA.tr), dA.ldT);
         w.out0 = h->grad() + d.master; w.ld0 = d.ld;
         if (adam) {
             w.out1 = p<void>(d.W); w.ld1 = d.ld;
@@ -369,20 +507,21 @@ struct Builder {
     }
 };
 
-inline bool is_gemm(int kind) { return kind <= K_WGRAD || kind == K_WGRAD_ADAM; }
+inline bool is_gemm(int kind) { return kind <= K_WGRAD || kind == K_WGRAD_ADAM || kind == K_DGRAD_F32; }
 
 // Fixes the tile configuration of one launch and lays its items' tiles out back to back.
 Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, int count, const std::string& name, int* next_slot) {
     Launch L;
     L.name = name; L.first = first; L.count = count;
-    bool need128 = false;
+    bool need128 = false, narrow = false;
     long tiles128 = 0;
     for (int i = first; i < first + count; ++i) {
         const WorkItem& w = items[i];
         if ((w.kind == K_FWD_HEAD || w.kind == K_DGRAD_LATENT) && 2 * w.nz > 64) need128 = true;
         if (is_gemm(w.kind)) tiles128 += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
+        if (is_gemm(w.kind) && (w.N <= 64 || w.M <= 64)) narrow = true;      // a 128-wide tile would be mostly padding
     }
-    L.cfg = (need128 || tiles128 >= 192) ? 1 : 0;
+    L.cfg = (need128 || (tiles128 >= 192 && !narrow)) ? 1 : 0;
     const int T = L.cfg ? 128 : 64;
     int base = 0;
     for (int i = first; i < first + count; ++i) {
@@ -432,41 +571,118 @@ void build_training_plan(avae_handle* h) {
         if (count <= 0) return;
         dst.push_back(finish_launch(h, h->items, first, count, name, &slot));
     };
+    // conv-branch helper launches (one segment per conv modality)
+    auto gather_launch = [&](const std::string& name, std::vector<Launch>& dst, auto&& stage_of, auto&& src_of) {
+        Launch L;
+        L.name = name; L.type = 1;
+        int base = 0;
+        for (Mod& md : h->mods) if (md.conv) {
+            GatherSeg g = bd.gather_seg(stage_of(md), src_of(md), true);
+            g.tile_base = base; base += g.tiles_r * g.tiles_c;
+            L.ga.seg[L.ga.n_seg++] = g;
+        }
+        L.blocks = base;
+        if (base > 0) dst.push_back(L);
+    };
+    auto col2im_launch = [&](const std::string& name, std::vector<Launch>& dst, auto&& stage_of, auto&& prev_of) {
+        Launch L;
+        L.name = name; L.type = 2;
+        int base = 0;
+        for (Mod& md : h->mods) if (md.conv) {
+            Col2imSeg c = bd.col2im_seg(stage_of(md), prev_of(md), md);
+            c.tile_base = base; base += c.tiles_r * c.tiles_c;
+            L.ca.seg[L.ca.n_seg++] = c;
+        }
+        L.blocks = base;
+        if (base > 0) dst.push_back(L);
+    };
+    bool any_conv = false;
+    for (const Mod& md : h->mods) any_conv = any_conv || md.conv;
     // ---- forward.  Modalities with fewer hidden layers simply sit out a launch; data dependencies
     // are per modality and launches are stream-ordered, so this is always safe.
     for (int k = 0; k < Lmax; ++k)
         group("fwd_enc" + std::to_string(k + 1), h->fwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.X0 : md.E[k - 1], md.enc[k], md.E[k]));
         });
+    if (any_conv) {   // conv encoder: (im2col, GEMM) x 3, then the patch matrix of the flatten+dense heads
+        for (int i = 0; i < 3; ++i) {
+            gather_launch("conv_enc" + std::to_string(i + 1) + "_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cenc[i]; },
+                          [&](Mod& md) { return i == 0 ? h->at<void>(md.X0.rm) : h->at<void>(md.cenc[i - 1].Y.rm); });
+            group("conv_enc" + std::to_string(i + 1), h->fwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_fwd(md.cenc[i])); });
+        }
+        gather_launch("conv_head_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cenc[3]; },
+                      [&](Mod& md) { return h->at<void>(md.cenc[2].Y.rm); });
+    }
     group("fwd_head", h->fwd, [&] { for (Mod& md : h->mods) h->items.push_back(bd.fwd_head(md, true)); });
-    for (int k = 0; k < Lmax; ++k)
+    for (int k = 0; k < std::max(Lmax, 1); ++k)
         group("fwd_dec" + std::to_string(k + 1), h->fwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k]));
             if (k == 0) h->items.push_back(bd.latent());     // needs every modality's (mu, lv): ready after fwd_head
         });
+    if (any_conv) {   // deconv decoder: (im2col of the dilated input, GEMM + bias + sigmoid) x 4, then flatten for the dense output
+        for (int i = 0; i < 4; ++i) {
+            gather_launch("conv_dec" + std::to_string(i + 1) + "_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
+                          [&](Mod& md) { return i == 0 ? h->at<void>(md.Z.rm) : h->at<void>(md.cdec[i - 1].Y.rm); });
+            group("conv_dec" + std::to_string(i + 1), h->fwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_fwd(md.cdec[i])); });
+        }
+        gather_launch("conv_out_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cdec[4]; },
+                      [&](Mod& md) { return h->at<void>(md.cdec[3].Y.rm); });
+    }
     group("fwd_out_loss", h->fwd, [&] { for (int m = 0; m < h->M; ++m) h->items.push_back(bd.fwd_out(h->mods[m], m, true)); });
-    // ---- backward: the dgrad chain (one launch per layer, both modalities), then EVERY weight
+    // ---- backward: the dgrad chain (one launch per layer, all modalities), then EVERY weight
     // gradient in one final wave of launches: they depend only on stored activations / activation
     // gradients, and being last lets the single-replica path fuse Adam + shadow refresh into their
     // epilogues (no launch reads a weight shadow afterwards, so updating in place is hazard-free).
-    group("bwd_out", h->bwd, [&] { for (Mod& md : h->mods) h->items.push_back(bd.dgrad_hidden(md.dO, md.outl, md.D.back(), md.dD.back())); });
+    // Conv stages go GEMM (fp32 patch gradients) -> k_col2im (sum + act' -> gradient of the producing stage).
+    group("bwd_out", h->bwd, [&] {
+        for (Mod& md : h->mods) {
+            if (md.conv) h->items.push_back(bd.conv_dgrad(md.cdec[4], md.dO));
+            else h->items.push_back(bd.dgrad_hidden(md.dO, md.outl, md.D.back(), md.dD.back()));
+        }
+    });
+    if (any_conv) {
+        for (int i = 4; i >= 1; --i) {       // stage i's patch gradients -> dY of stage i-1; then stage i-1's dgrad GEMM
+            col2im_launch("conv_dec" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
+                          [&](Mod& md) -> const ConvStage* { return &md.cdec[i - 1]; });
+            group("conv_bwd_dec" + std::to_string(i), h->bwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_dgrad(md.cdec[i - 1], md.cdec[i - 1].dY)); });
+        }
+        // first decoder stage: its input is z -> latent mode turns dz into [dmu | dlv]
+        col2im_launch("conv_dec1_latent", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[0]; },
+                      [&](Mod&) -> const ConvStage* { return nullptr; });
+    }
     for (int k = Lmax - 1; k >= 1; --k)
         group("bwd_dec" + std::to_string(k + 1), h->bwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.dgrad_hidden(md.dD[k], md.dec[k], md.D[k - 1], md.dD[k - 1]));
         });
-    group("bwd_dec1_latent", h->bwd, [&] { for (Mod& md : h->mods) h->items.push_back(bd.dgrad_latent(md)); });
+    group("bwd_dec1_latent", h->bwd, [&] { for (Mod& md : h->mods) if (!md.conv) h->items.push_back(bd.dgrad_latent(md)); });
     group("bwd_head", h->bwd, [&] {
-        for (Mod& md : h->mods) h->items.push_back(bd.dgrad_hidden(md.dH, md.head, md.E.back(), md.dE.back()));
-        if (Lmax == 1) h->items.push_back(bd.cost(true));
+        for (Mod& md : h->mods) {
+            if (md.conv) h->items.push_back(bd.conv_dgrad(md.cenc[3], md.dH));
+            else h->items.push_back(bd.dgrad_hidden(md.dH, md.head, md.E.back(), md.dE.back()));
+        }
+        h->items.push_back(bd.cost(true));                       // every cost partial is final by now: cost, step counter, lr_t
     });
+    if (any_conv) {
+        for (int i = 3; i >= 1; --i) {
+            col2im_launch("conv_enc" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cenc[i]; },
+                          [&](Mod& md) -> const ConvStage* { return &md.cenc[i - 1]; });
+            if (i >= 2) group("conv_bwd_enc" + std::to_string(i), h->bwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_dgrad(md.cenc[i - 1], md.cenc[i - 1].dY)); });
+        }
+    }
     for (int k = Lmax - 1; k >= 1; --k)
         group("bwd_enc" + std::to_string(k + 1), h->bwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.dgrad_hidden(md.dE[k], md.enc[k], md.E[k - 1], md.dE[k - 1]));
-            if (k == 1) h->items.push_back(bd.cost(true));       // last launch of the chain: cost, step counter, lr_t
         });
     for (int fused = 0; fused < 2; ++fused) {
         std::vector<WorkItem> wg;
         for (Mod& md : h->mods) {
+            if (md.conv) {
+                wg.push_back(bd.wgrad(md.cdec[4].P, md.cdec[4].d, md.dO, fused));
+                for (int i = 3; i >= 0; --i) wg.push_back(bd.wgrad(md.cdec[i].P, md.cdec[i].d, md.cdec[i].dY, fused));
+                wg.push_back(bd.wgrad(md.cenc[3].P, md.cenc[3].d, md.dH, fused));
+                for (int i = 2; i >= 0; --i) wg.push_back(bd.wgrad(md.cenc[i].P, md.cenc[i].d, md.cenc[i].dY, fused));
+                continue;
+            }
             wg.push_back(bd.wgrad(md.D.back(), md.outl, md.dO, fused));
             for (int k = md.L - 1; k >= 1; --k) wg.push_back(bd.wgrad(md.D[k - 1], md.dec[k], md.dD[k], fused));
             wg.push_back(bd.wgrad(md.Z, md.dec[0], md.dD[0], fused));
@@ -506,6 +722,11 @@ void build_training_plan(avae_handle* h) {
         h->adam_items.push_back(a);
     };
     for (const Mod& md : h->mods) {
+        if (md.conv) {
+            for (const ConvStage& st : md.cenc) add(st.d);
+            for (const ConvStage& st : md.cdec) add(st.d);
+            continue;
+        }
         for (const Dense& d : md.enc) add(d);
         add(md.head);
         for (const Dense& d : md.dec) add(d);
@@ -525,9 +746,32 @@ void build_inference(avae_handle* h, int m, bool enc, int rows) {
         inf.items.push_back(w);
         inf.launches.push_back(finish_launch(h, inf.items, (int)inf.items.size() - 1, 1, name, &slot));
     };
-    if (enc) {
+    auto gather1 = [&](const ConvStage& st, const void* src, const std::string& name) {
+        Launch L;
+        L.name = name; L.type = 1;
+        GatherSeg g = bd.gather_seg(st, src, false);      // inference never touches the transposed (K = batch) copies
+        g.tile_base = 0;
+        L.ga.seg[0] = g; L.ga.n_seg = 1;
+        L.blocks = g.tiles_r * g.tiles_c;
+        inf.launches.push_back(L);
+    };
+    if (enc && md.conv) {
+        for (int i = 0; i < 3; ++i) {
+            gather1(md.cenc[i], i == 0 ? h->at<void>(md.X0.rm) : h->at<void>(md.cenc[i - 1].Y.rm), "inf_conv_im2col");
+            one(bd.conv_fwd(md.cenc[i]), "inf_conv_enc");
+        }
+        gather1(md.cenc[3], h->at<void>(md.cenc[2].Y.rm), "inf_conv_im2col");
+        one(bd.fwd_head(md, true), "inf_head");
+    } else if (enc) {
         for (int k = 0; k < md.L; ++k) one(bd.fwd_hidden(k == 0 ? md.X0 : md.E[k - 1], md.enc[k], md.E[k]), "inf_enc");
         one(bd.fwd_head(md, true), "inf_head");
+    } else if (md.conv) {
+        for (int i = 0; i < 4; ++i) {
+            gather1(md.cdec[i], i == 0 ? h->at<void>(md.Z.rm) : h->at<void>(md.cdec[i - 1].Y.rm), "inf_conv_im2col");
+            one(bd.conv_fwd(md.cdec[i]), "inf_conv_dec");
+        }
+        gather1(md.cdec[4], h->at<void>(md.cdec[3].Y.rm), "inf_conv_im2col");
+        one(bd.fwd_out(md, m, false), "inf_out");
     } else {
         for (int k = 0; k < md.L; ++k) one(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k]), "inf_dec");
         one(bd.fwd_out(md, m, false), "inf_out");
@@ -565,9 +809,21 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
 #ifdef AVAE_STAMPS
         if (stamp_base >= 0) stamps = h->at<unsigned long long>(h->off_stamps);
 #endif
-        launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.blocks, L.lds, h->state(), s, stamps, stamp_base + k);
+        if (L.type == 1) launch_gather(h->cfg.compute_dtype, L.ga, L.blocks, s);
+        else if (L.type == 2) launch_col2im(h->cfg.compute_dtype, L.ca, L.blocks, s);
+        else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.blocks, L.lds, h->state(), s, stamps, stamp_base + k);
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to
-            std::fprintf(stderr, "[avae] launch %s cfg=%d items=%d blocks=%d\n", L.name.c_str(), L.cfg, L.count, L.blocks);
+            std::fprintf(stderr, "[avae] launch %s type=%d cfg=%d items=%d blocks=%d\n", L.name.c_str(), L.type, L.cfg, L.count, L.blocks);
+            for (int i = 0; i < L.args.n_items && L.type == 0; ++i)
+                std::fprintf(stderr, "        item kind=%d M=%d N=%d K=%d lda=%d ldb=%d tiles=%dx%d base=%d\n", L.args.items[i].kind, L.args.items[i].M,
+                             L.args.items[i].N, L.args.items[i].K, L.args.items[i].lda, L.args.items[i].ldb, L.args.items[i].tiles_m, L.args.items[i].tiles_n, L.args.items[i].tile_base);
+            for (int i = 0; i < L.ga.n_seg && L.type == 1; ++i)
+                std::fprintf(stderr, "        gather B=%d IH=%d Cin=%d OH=%d k=%d so=%d d=%d pad=%d sb=%d sp=%d ones=%d ldp=%d ldpt=%d Pt=%p tiles=%dx%d\n", L.ga.seg[i].g.B, L.ga.seg[i].g.IH,
+                             L.ga.seg[i].g.Cin, L.ga.seg[i].g.OH, L.ga.seg[i].g.k, L.ga.seg[i].g.so, L.ga.seg[i].g.d, L.ga.seg[i].g.pad, L.ga.seg[i].g.src_sb, L.ga.seg[i].g.src_sp,
+                             L.ga.seg[i].g.ones, L.ga.seg[i].ldp, L.ga.seg[i].ldpt, L.ga.seg[i].Pt, L.ga.seg[i].tiles_r, L.ga.seg[i].tiles_c);
+            for (int i = 0; i < L.ca.n_seg && L.type == 2; ++i)
+                std::fprintf(stderr, "        col2im B=%d IH=%d Cin=%d OH=%d k=%d lddp=%d lda=%d ldat=%d dAt=%p g0=%p tiles=%dx%d\n", L.ca.seg[i].g.B, L.ca.seg[i].g.IH, L.ca.seg[i].g.Cin,
+                             L.ca.seg[i].g.OH, L.ca.seg[i].g.k, L.ca.seg[i].lddp, L.ca.seg[i].lda, L.ca.seg[i].ldat, L.ca.seg[i].dAt, (const void*)L.ca.seg[i].g0, L.ca.seg[i].tiles_r, L.ca.seg[i].tiles_c);
             std::fflush(stderr);
             HIP_OK(hipStreamSynchronize(s));
         }

@@ -714,6 +714,7 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
                                                 M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
         if (w.out1) transposed_store<CT, BM, BN>(Zs, reinterpret_cast<CT*>(w.out1), w.ld1, M, 2 * nz, m0, 0);
     } break;
+    case K_DGRAD_F32:
     case K_WGRAD: {
         float* G = reinterpret_cast<float*>(w.out0);
         tile_pass<float, float, false, false, BM, BN>(Cs, G, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
@@ -922,6 +923,152 @@ void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s) {
     if (n_blocks <= 0) return;
     if (compute_dtype == AVAE_BF16) hipLaunchKernelGGL((k_prep<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
     else hipLaunchKernelGGL((k_prep<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+}
+
+// ------------------------------------------------------------------ conv branch: im2col / col2im
+template <typename CT> __device__ __forceinline__ float ct_load(const CT* p);
+template <> __device__ __forceinline__ float ct_load<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ct_load<__bf16>(const __bf16* p) { return (float)*p; }
+
+// Patch matrix of one conv-like layer, 64 x 64 tiles (rows = output pixels, cols = (kh,kw,ci) [+ ones]).
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
+    __shared__ float T[64][65];
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].tile_base) it = i;
+    const GatherSeg& w = a.seg[it];
+    const ConvGeom g = w.g;
+    const int t = bid - w.tile_base;
+    const int tr = t / w.tiles_c, tc = t - tr * w.tiles_c;
+    const int r0 = tr * 64, c0 = tc * 64;
+    const int M = g.B * g.OH * g.OW, K = g.k * g.k * g.Cin, KC = K + (g.ones ? 1 : 0);
+    const CT* src = reinterpret_cast<const CT*>(w.src);
+    const int c4 = (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 4) + 16 * i;
+        const int m = r0 + r, kc = c0 + c4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < M && kc < KC) {
+            const int b = m / (g.OH * g.OW), rem = m - b * g.OH * g.OW, oh = rem / g.OW, ow = rem - oh * g.OW;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kidx = kc + e;
+                if (kidx < K) {
+                    const int kpos = kidx / g.Cin, ci = kidx - kpos * g.Cin, kh = kpos / g.k, kw = kpos - kh * g.k;
+                    const int nh = oh * g.so + kh - g.pad, nw = ow * g.so + kw - g.pad;
+                    if (nh >= 0 && nw >= 0 && nh % g.d == 0 && nw % g.d == 0) {
+                        const int ih = nh / g.d, iw = nw / g.d;
+                        if (ih < g.IH && iw < g.IW)
+                            v[e] = ct_load<CT>(src + (size_t)b * g.src_sb + (size_t)(ih * g.IW + iw) * g.src_sp + ci);
+                    }
+                } else if (kidx == K && g.ones) {
+                    v[e] = 1.0f;
+                }
+            }
+            store_row<CT>(reinterpret_cast<CT*>(w.P) + (size_t)m * w.ldp + kc, v, KC - kc);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[r][c4 + e] = v[e];
+    }
+    if (!w.Pt) return;
+    lds_barrier();
+    const int r4 = (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (tid >> 4) + 16 * i;
+        const int kc = c0 + c, m = r0 + r4;
+        if (kc < KC && m < M) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = T[r4 + e][c];
+            store_row<CT>(reinterpret_cast<CT*>(w.Pt) + (size_t)kc * w.ldpt + m, v, M - m);
+        }
+    }
+}
+
+// Gradient of a conv-like layer's input from its fp32 patch gradients: every input element sums the
+// patch entries that were gathered from it (no atomics), then the producing layer's act' is applied.
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
+    __shared__ float T[64][65];
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].tile_base) it = i;
+    const Col2imSeg& w = a.seg[it];
+    const ConvGeom g = w.g;
+    const int t = bid - w.tile_base;
+    const int tr = t / w.tiles_c, tc = t - tr * w.tiles_c;
+    const int r0 = tr * 64, c0 = tc * 64;
+    const int R = g.B * g.IH * g.IW;                      // input pixels
+    const bool latent = w.g0 != nullptr;
+    const int C = latent ? 2 * w.nz : g.Cin;              // output columns
+    const int c4 = (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 4) + 16 * i;
+        const int pix = r0 + r, cc = c0 + c4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pix < R && cc < C) {
+            const int b = pix / (g.IH * g.IW), rem = pix - b * g.IH * g.IW, ih = rem / g.IW, iw = rem - ih * g.IW;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = cc + e;
+                if (col >= C) continue;
+                const int ci = latent ? (col < w.nz ? col : col - w.nz) : col;
+                float acc = 0.0f;
+                for (int kh = 0; kh < g.k; ++kh) {
+                    const int nh = ih * g.d + g.pad - kh;
+                    if (nh < 0 || nh % g.so) continue;
+                    const int oh = nh / g.so;
+                    if (oh >= g.OH) continue;
+                    for (int kw = 0; kw < g.k; ++kw) {
+                        const int nw = iw * g.d + g.pad - kw;
+                        if (nw < 0 || nw % g.so) continue;
+                        const int ow = nw / g.so;
+                        if (ow >= g.OW) continue;
+                        acc += w.dP[(size_t)((b * g.OH + oh) * g.OW + ow) * w.lddp + (kh * g.k + kw) * g.Cin + ci];
+                    }
+                }
+                if (latent) {        // dmu = dz + g0mu ; dlv = dz * F + g0lv   (g0 = [g0mu | g0lv | F], reparameterisation)
+                    const float* gr = w.g0 + (size_t)pix * 3 * w.nz;
+                    acc = col < w.nz ? acc + gr[ci] : acc * gr[2 * w.nz + ci] + gr[w.nz + ci];
+                } else if (w.yprev) {
+                    acc *= act_bwd(w.act, ct_load<CT>(reinterpret_cast<const CT*>(w.yprev) + (size_t)pix * w.ldy + ci));
+                }
+                v[e] = acc;
+            }
+            store_row<CT>(reinterpret_cast<CT*>(w.dA) + (size_t)pix * w.lda + cc, v, C - cc);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[r][c4 + e] = v[e];
+    }
+    if (!w.dAt) return;
+    lds_barrier();
+    const int r4 = (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (tid >> 4) + 16 * i;
+        const int cc = c0 + c, pix = r0 + r4;
+        if (cc < C && pix < R) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = T[r4 + e][c];
+            store_row<CT>(reinterpret_cast<CT*>(w.dAt) + (size_t)cc * w.ldat + pix, v, R - pix);
+        }
+    }
+}
+
+void launch_gather(int compute_dtype, const GatherArgs& a, int n_blocks, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    if (compute_dtype == AVAE_BF16) hipLaunchKernelGGL((k_gather<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((k_gather<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+}
+void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    if (compute_dtype == AVAE_BF16) hipLaunchKernelGGL((k_col2im<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((k_col2im<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
 // ------------------------------------------------------------------ strided fill (constant-1 columns)

@@ -14,7 +14,8 @@ Deliberate, documented differences from the reference:
   * ``partial_fit`` / ``evaluate_cost`` / ``reconstruct`` accept an optional explicit ``eps``
     (the reference draws it inside the graph, :90); ``None`` uses the in-kernel Philox stream.
   * network dicts may carry an extra key ``n_hidden`` (list) for more than two hidden layers.
-  * ``hidden_conv=True`` (conv/deconv branch, :169-210,:249-291) raises: not built yet.
+  * ``hidden_conv=True`` (conv encoder :169-210 / deconv decoder :249-291, deconv.py) is built for what
+    the reference's branch can express: a binary 28x28 modality (n_input = 784).
 """
 import ctypes as C
 import datetime
@@ -59,7 +60,16 @@ def hidden_sizes(na):
 
 def layer_shapes(na):
     """Flat-parameter layout of one modality in the reference's variable-creation order
-    (vae_assoc.py:185-215,257-300): [(name, shape), ...]."""
+    (vae_assoc.py:185-215,257-300; conv branch :174-210,:251-300): [(name, shape), ...]."""
+    if na.get("hidden_conv"):
+        r1, r2 = int(na["n_hidden_recog_1"]), int(na["n_hidden_recog_2"])
+        g1, g2 = int(na["n_hidden_gener_1"]), int(na["n_hidden_gener_2"])
+        n_in, n_z = int(na["n_input"]), int(na["n_z"])
+        shapes = [("enc_C1", (5, 5, 1, r1)), ("enc_C2", (5, 5, r1, 2 * r1)), ("enc_C3", (5, 5, 2 * r1, r2)),
+                  ("enc_Wmu", (9 * r2, n_z)), ("enc_bmu", (n_z,)), ("enc_Wsig", (9 * r2, n_z)), ("enc_bsig", (n_z,))]
+        for i, (k, co, ci) in enumerate(((3, g1, n_z), (5, g1 // 2, g1), (5, g2, g1 // 2), (5, 1, g2))):
+            shapes += [("dec_T%d_W" % (i + 1), (k, k, co, ci)), ("dec_T%d_b" % (i + 1), (co,))]
+        return shapes + [("dec_Wout", (n_in, n_in)), ("dec_bout", (n_in,))]
     hs = hidden_sizes(na)
     n_in, n_z = int(na["n_input"]), int(na["n_z"])
     shapes, prev = [], n_in
@@ -114,8 +124,8 @@ class AssocVariationalAutoEncoder(object):
         for na in network_architectures:
             if int(na["n_z"]) != self.n_z:
                 raise ValueError("all modalities must share n_z (the reference builds one eps of modality 0's n_z, :89-91)")
-            if na.get("hidden_conv"):
-                raise NotImplementedError("hidden_conv=True (conv/deconv branch) is not built yet")
+            if na.get("hidden_conv") and int(na["n_input"]) != 784:
+                raise ValueError("hidden_conv=True needs n_input = 784: the reference's branch is hard-wired to 28x28 images")
         if compute_dtype not in _capi.DTYPE_IDS:
             raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
         self.compute_dtype = compute_dtype
@@ -142,7 +152,14 @@ class AssocVariationalAutoEncoder(object):
                 cfg.mod[m].n_hidden[k] = hsz
             cfg.mod[m].binary = 1 if self.binary[m] else 0
             cfg.mod[m].weight = float(self.weights[m])
-            cfg.mod[m].hidden_conv = 0
+            cfg.mod[m].hidden_conv = 1 if na.get("hidden_conv") else 0
+            if na.get("hidden_conv"):
+                if not self.binary[m]:
+                    raise ValueError("hidden_conv=True needs a binary modality (the reference's non-binary conv decoder "
+                                     "is shape-broken, vae_assoc.py:299)")
+                cfg.mod[m].n_hidden_layers = 2
+                cfg.mod[m].n_hidden[0], cfg.mod[m].n_hidden[1] = int(na["n_hidden_recog_1"]), int(na["n_hidden_recog_2"])
+                cfg.mod[m].conv_gener[0], cfg.mod[m].conv_gener[1] = int(na["n_hidden_gener_1"]), int(na["n_hidden_gener_2"])
         cfg.n_z = self.n_z
         cfg.batch_size = self.batch_size
         cfg.batch_global = self.batch_size * world
@@ -183,9 +200,23 @@ class AssocVariationalAutoEncoder(object):
         rng = np.random.RandomState(int(seed) & 0x7FFFFFFF)
         flat = []
         for na in network_architectures:
-            for _, shp in layer_shapes(na):
-                flat.append(xavier_init(shp[0], shp[1], rng=rng).reshape(-1) if len(shp) == 2
-                            else np.zeros(shp, dtype=np.float32))
+            for name, shp in layer_shapes(na):
+                if len(shp) == 2:
+                    flat.append(xavier_init(shp[0], shp[1], rng=rng).reshape(-1))
+                elif len(shp) == 4 and name.startswith("enc_C"):
+                    # weight_variable (vae_assoc.py:471-473): truncated_normal(stddev=0.1)
+                    w = rng.standard_normal(shp)
+                    while np.any(np.abs(w) > 2):
+                        bad = np.abs(w) > 2
+                        w[bad] = rng.standard_normal(int(bad.sum()))
+                    flat.append((0.1 * w).astype(np.float32).reshape(-1))
+                elif len(shp) == 4:
+                    # deconv.py:83-84: xavier over (out_depth*k*k, in_depth*k*k)
+                    kk = shp[0] * shp[1]
+                    lim = np.sqrt(6.0 / (shp[2] * kk + shp[3] * kk))
+                    flat.append(rng.uniform(-lim, lim, size=shp).astype(np.float32).reshape(-1))
+                else:
+                    flat.append(np.zeros(shp, dtype=np.float32))
         self.set_params(np.concatenate(flat))
 
     # ------------------------------------------------------------------ plumbing
