@@ -44,3 +44,13 @@ def test_labels_travel_with_data():
 def test_split_points():
     ds = dataset.construct_datasets(np.zeros((25, 2)), shuffle=False)
     assert (ds.train._data.shape[0], ds.validation._data.shape[0], ds.test._data.shape[0]) == (20, 2, 3)
+
+
+def test_extractors_follow_reference_key_orders():
+    """utils.py:153 sorts by the last key character, :186 by the whole key; digits only by default."""
+    d = {"b_1": [np.full((2, 2), 10)], "a_2": [np.full((2, 2), 20)], "c_a": [np.full((2, 2), 30)]}
+    imgs = dataset.extract_images(d)
+    assert imgs.shape == (2, 4) and np.allclose(imgs[:, 0], [10 / 255., 20 / 255.])          # "..1" before "..2"
+    fa, mean, std = dataset.extract_jnt_fa_parms({k: [v[0].ravel().astype(float)] for k, v in d.items()})
+    assert np.allclose(fa[:, 0], [20, 10]) and np.allclose(mean, 15) and np.allclose(std, 5)   # "a_2" before "b_1"
+    assert dataset.extract_images(d, only_digits=False).shape[0] == 3

@@ -501,6 +501,33 @@ def test_train_loop_matches_oracle_loop(V):
     assert np.abs(p_hip - p_ref).max() <= 5e-5
 
 
+def test_device_resident_dataset_same_order_and_costs(V):
+    """dataset.DeviceDataSet: same batch order as the host DataSet (fixture-pinned to the reference), and
+    train() on it gives the same cost history as on host batches."""
+    from vae_assoc_amd import dataset
+    archs = [make_arch("image", 784, 16, 12, 4), make_arch("joint", 147, 12, 8, 4)]
+    rng = np.random.default_rng(6)
+    data = np.concatenate(synth_batch(rng, 150, [784, 147], [True, False]), axis=1)
+    np.random.seed(5)                                     # the two share numpy's global RNG: run them one after the other
+    host = dataset.DataSet(data.copy())
+    want = [host.next_batch(32)[0].copy() for _ in range(12)]      # wraps twice over 150 rows
+    np.random.seed(5)
+    devd = dataset.DeviceDataSet(data.copy())
+    for a in want:
+        b, _l = devd.next_batch(32)
+        assert b.is_cuda and np.array_equal(a, b.cpu().numpy())
+    hists = []
+    for on_device in (False, True):
+        np.random.seed(11)
+        ds = dataset.construct_datasets(data.copy())
+        if on_device:
+            ds = dataset.to_device(ds)
+        _m, hist = V.train(ds, archs, binary=[True, False], batch_size=20, training_epochs=2, display_step=10,
+                           compute_dtype="fp32", seed=3)
+        hists.append(hist)
+    assert hists[0] == hists[1]
+
+
 def test_early_stop_runs(V, capsys):
     from vae_assoc_amd import dataset
     archs = [make_arch("image", 784, 16, 12, 4), make_arch("joint", 147, 12, 8, 4)]

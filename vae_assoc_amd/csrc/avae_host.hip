@@ -1215,7 +1215,7 @@ int avae_reconstruct(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld
     });
 }
 
-// ---- checkpoint: "AVAECKPT" | u32 version | u32 n_mod | u32 n_z | per modality {n_input, L, hs[L]} | u64 P | i64 step | theta | m | v
+// ---- checkpoint: "AVAECKPT" | u32 version | u32 n_mod | u32 n_z | per modality {n_input, L, hs[L], conv, gener1, gener2} | u64 P | i64 step | theta | m | v
 int avae_save(avae_handle* h, const char* path) {
     return guarded(h, [&] {
         std::vector<float> I, th(h->P_flat), mm(h->P_flat), vv(h->P_flat);
@@ -1228,8 +1228,12 @@ int avae_save(avae_handle* h, const char* path) {
         if (!f) throw Err(std::string("cannot open for writing: ") + path);
         auto w32 = [&](uint32_t v) { std::fwrite(&v, 4, 1, f); };
         std::fwrite("AVAECKPT", 1, 8, f);
-        w32(1); w32((uint32_t)h->M); w32((uint32_t)h->nz);
-        for (const Mod& md : h->mods) { w32((uint32_t)md.n_in); w32((uint32_t)md.L); for (int x : md.hs) w32((uint32_t)x); }
+        w32(2); w32((uint32_t)h->M); w32((uint32_t)h->nz);
+        for (int m = 0; m < h->M; ++m) {
+            const Mod& md = h->mods[m];
+            w32((uint32_t)md.n_in); w32((uint32_t)md.hs.size()); for (int x : md.hs) w32((uint32_t)x);
+            w32(md.conv ? 1u : 0u); w32((uint32_t)h->cfg.mod[m].conv_gener[0]); w32((uint32_t)h->cfg.mod[m].conv_gener[1]);
+        }
         uint64_t P = h->P_flat; std::fwrite(&P, 8, 1, f);
         int64_t st = step; std::fwrite(&st, 8, 1, f);
         bool ok = std::fwrite(th.data(), 4, P, f) == P && std::fwrite(mm.data(), 4, P, f) == P && std::fwrite(vv.data(), 4, P, f) == P;
@@ -1248,11 +1252,16 @@ int avae_load(avae_handle* h, const char* path) {
             char magic[8];
             auto r32 = [&]() { uint32_t v = 0; if (std::fread(&v, 4, 1, f) != 1) throw Err("truncated checkpoint"); return v; };
             if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "AVAECKPT", 8) != 0) throw Err("not an AVAE checkpoint");
-            if (r32() != 1) throw Err("unsupported checkpoint version");
+            if (r32() != 2) throw Err("unsupported checkpoint version");
             if ((int)r32() != h->M || (int)r32() != h->nz) throw Err("checkpoint architecture mismatch (modalities / n_z)");
-            for (const Mod& md : h->mods) {
-                if ((int)r32() != md.n_in || (int)r32() != md.L) throw Err("checkpoint architecture mismatch (n_input / depth)");
+            for (int m = 0; m < h->M; ++m) {
+                const Mod& md = h->mods[m];
+                if ((int)r32() != md.n_in || r32() != (uint32_t)md.hs.size()) throw Err("checkpoint architecture mismatch (n_input / depth)");
                 for (int x : md.hs) if ((int)r32() != x) throw Err("checkpoint architecture mismatch (hidden width)");
+                const bool conv = r32() != 0;
+                const int g1 = (int)r32(), g2 = (int)r32();
+                if (conv != md.conv || (conv && (g1 != h->cfg.mod[m].conv_gener[0] || g2 != h->cfg.mod[m].conv_gener[1])))
+                    throw Err("checkpoint architecture mismatch (conv branch)");
             }
             uint64_t P = 0;
             if (std::fread(&P, 8, 1, f) != 1 || P != h->P_flat) throw Err("checkpoint parameter count mismatch");

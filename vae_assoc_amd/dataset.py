@@ -6,6 +6,12 @@ old order is discarded.  ``construct_datasets`` (:45-72): optional shuffle, then
 int((1-val-test)*N) and int((1-test)*N).  The reference's labelled path is broken (it never
 sets ``_num_examples`` when labels are given, :8-15, and slices labels wrongly at :65); here
 labels simply work.
+
+``DeviceDataSet`` keeps the sample matrix resident in HBM with the SAME batch order (the
+permutation still comes from ``np.random.shuffle`` on the host; only the gather runs on the GPU),
+so ``train()`` feeds the step by pointer + row stride without a host->device copy per step.
+``extract_images`` / ``extract_jnt_fa_parms`` mirror the reference's pickle-schema readers
+(/root/reference/utils.py:142-158, 178-195) on an already-loaded ``{char_key: [arrays]}`` dict.
 """
 import numpy as np
 
@@ -64,3 +70,62 @@ def construct_datasets(data, labels=None, shuffle=True, validation_ratio=.1, tes
                                    lab(validation_start_idx, test_start_idx))
     data_sets.test = DataSet(data_shuffled[test_start_idx:, :], lab(test_start_idx, n))
     return data_sets
+
+
+class DeviceDataSet(DataSet):
+    """DataSet whose ``_data`` is a torch tensor on the GPU; ``next_batch`` returns device views."""
+
+    def __init__(self, data, labels=None, device=None):
+        import torch
+        if not torch.is_tensor(data):
+            data = torch.as_tensor(np.ascontiguousarray(data, dtype=np.float32))
+        data = data.to(device if device is not None else "cuda", dtype=torch.float32)
+        DataSet.__init__(self, data, labels)
+
+    def next_batch(self, batch_size):
+        import torch
+        start = self._index_in_epoch
+        self._index_in_epoch += batch_size
+        if self._index_in_epoch > self._num_examples:
+            self._epochs_completed += 1
+            perm = np.arange(self._num_examples)
+            np.random.shuffle(perm)                   # same host RNG stream as the reference (dataset.py:30-31)
+            self._data = self._data[torch.as_tensor(perm, device=self._data.device)]
+            if self._labels is not None:
+                self._labels = self._labels[perm]
+            start = 0
+            self._index_in_epoch = batch_size
+            assert batch_size <= self._num_examples
+        end = self._index_in_epoch
+        return self._data[start:end], (self._labels[start:end] if self._labels is not None else None)
+
+
+def to_device(data_sets, device=None):
+    """Move the three splits of ``construct_datasets`` into HBM (same order, same batching)."""
+    out = DataSets()
+    for name in ("train", "validation", "test"):
+        ds = getattr(data_sets, name)
+        setattr(out, name, DeviceDataSet(ds._data, ds._labels, device))
+    return out
+
+
+def extract_images(data, only_digits=True, dtype=np.float32):
+    """utils.py:142-158: characters ordered by their LAST key character, images flattened and scaled by 1/255."""
+    images = []
+    for char in sorted(data.keys(), key=lambda k: k[-1]):
+        if only_digits and ord(char[-1]) > 57:
+            continue
+        images += [np.asarray(d).flatten().astype(dtype) * 1. / 255. for d in data[char]]
+    return np.array(images)
+
+
+def extract_jnt_fa_parms(data, only_digits=True):
+    """utils.py:178-195: characters ordered by the WHOLE key (note: not the order extract_images uses --
+    pairing the two relies on both orders agreeing, as in the reference); returns (parms, mean, std)."""
+    fa_parms = []
+    for char in sorted(data.keys()):
+        if only_digits and ord(char[-1]) > 57:
+            continue
+        fa_parms += [d for d in data[char]]
+    fa_parms = np.array(fa_parms)
+    return fa_parms, np.mean(fa_parms, axis=0), np.std(fa_parms, axis=0)

@@ -457,7 +457,9 @@ def train(data_sets, network_architectures, binary=True, weights=1.0, assoc_lamb
     hist_cap = 4096
 
     def seg(batch_xs):
-        t = torch.as_tensor(np.ascontiguousarray(batch_xs, dtype=np.float32)).to(dev)
+        # host batches (reference DataSet) are uploaded once per step; a dataset.DeviceDataSet hands device rows
+        t = batch_xs if torch.is_tensor(batch_xs) else torch.as_tensor(np.ascontiguousarray(batch_xs, dtype=np.float32))
+        t = t.to(dev)
         return [t[:, sens_indices[k]:sens_indices[k + 1]] for k in range(n_mod)]
 
     for epoch in range(training_epochs):
