@@ -142,7 +142,8 @@ int avae_load(avae_handle* h, const char* path);
 int avae_synchronize(avae_handle* h);
 /* Average device time (ms) of the kernels of one class over the calls since the last reset,
  * measured with hipEvents on the stream the kernels were launched on.  Only recorded while
- * timing is enabled (it forces eager launches instead of graph replay). */
+ * timing is enabled (it forces eager launches instead of graph replay).  Values are raw brackets
+ * (they include the dispatch latency); "_null_kernel_bracket" is the same bracket around a null kernel. */
 int avae_timing_enable(avae_handle* h, int32_t on);
 int avae_timing_report(avae_handle* h, char* buf, size_t buf_bytes);
 /* Copies a named internal fp32 tensor to the host (tests): "mulv<m>" [batch,2*n_z], "eps" [batch,n_z]. */
