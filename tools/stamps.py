@@ -38,7 +38,7 @@ def main():
     for i in range(300 if cfg != "c4" else 20):
         model.partial_fit(batches[i % 4], return_cost=False)
     torch.cuda.synchronize()
-    nl, nb, nw = 16, 512, 8
+    nl, nb, nw = 32, 1024, 8
     buf = np.zeros(nl * nb * nw, dtype=np.uint64)
     cnt = C.c_size_t(0)
     rc = model._L.avae_debug_fetch(model._h, b"stamps", buf.ctypes.data_as(C.c_void_p), buf.size * 2, C.byref(cnt))
@@ -51,7 +51,8 @@ def main():
     prev_end = None
     if cfg == "c4":
         names = ['fwd_enc1', 'fwd_enc2', 'fwd_enc3', 'fwd_enc4', 'fwd_head', 'fwd_dec1', 'fwd_dec2', 'fwd_dec3', 'fwd_dec4',
-                 'fwd_out_loss', 'bwd_out', 'bwd_dec4', 'bwd_dec3', 'bwd_dec2', 'bwd_dec1_latent', 'bwd_head']
+                 'fwd_out_loss', 'bwd_out', 'bwd_dec4', 'bwd_dec3', 'bwd_dec2', 'bwd_dec1_latent', 'bwd_head',
+                 'bwd_enc4', 'bwd_enc3', 'bwd_enc2', 'wgrad_adam1', 'wgrad_adam2']
     for l in range(min(nl, len(names))):
         s = st[l]
         live = s[:, 0] > 0

@@ -71,7 +71,8 @@ constexpr int kMaxItemsPerLaunch = 12;
 struct LaunchArgs {
     int n_items;
     int base[kMaxItemsPerLaunch];
-    int pad[3];
+    int stagger_sleeps;                     // > 0: workgroups 256..511 (the second resident slot of every CU) start that many
+    int pad[2];                             //      s_sleep(127) periods late, see k_grouped
     WorkItem items[kMaxItemsPerLaunch];
 };
 
@@ -170,7 +171,7 @@ void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStre
 // Diagnostic build only (-DAVAE_STAMPS): thread 0 of every block records s_memrealtime (100 MHz)
 // at kernel entry / after the item lookup / after the first staged tile / after the K loop / at
 // the end, plus s_memtime (shader clock) at entry and end.  No stamp executes in the product build.
-constexpr int kStampLaunches = 16, kStampBlocks = 512, kStampWords = 8;
+constexpr int kStampLaunches = 32, kStampBlocks = 1024, kStampWords = 8;
 
 // launchers implemented in avae_kernels.hip
 int tile_lds_bytes(int tile_cfg, bool two_c_tiles);

@@ -553,6 +553,15 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
     if (count > kMaxItemsPerLaunch) throw Err("internal error: too many items in one launch");
     std::memset(&L.args, 0, sizeof(L.args));
     L.args.n_items = count;
+    {   // see k_grouped: stagger the second resident slot when a 128x128-tile launch of fused weight gradients runs several rounds
+        bool all_wga = L.cfg == 1 && L.blocks > 2 * 256;
+        int nk_max = 0;
+        for (int i = first; i < first + count; ++i) {
+            all_wga = all_wga && items[i].kind == K_WGRAD_ADAM;
+            nk_max = std::max(nk_max, items[i].K / h->KU);
+        }
+        if (all_wga) L.args.stagger_sleeps = std::max(1, nk_max / 6);     // ~3.4 us per sleep period: about half of a tile's K loop
+    }
     for (int i = 0; i < count; ++i) { L.args.base[i] = items[first + i].tile_base; L.args.items[i] = items[first + i]; }
     if (*next_slot > h->n_partial) throw Err("internal error: cost partial slots overflow");
     return L;

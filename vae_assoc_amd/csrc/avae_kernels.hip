@@ -452,6 +452,13 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
     for (int i = 1; i < kMaxItemsPerLaunch; ++i)
         if (i < args.n_items && bid >= args.base[i]) it = i;     // bases ascend; everything is a kernel argument
     const WorkItem w = args.items[it];                            // one burst of scalar loads from the kernarg segment
+    // Multi-round launches of long weight-gradient tiles (two resident workgroups per CU): the MFMA-bound K loop
+    // is followed by an HBM-bound Adam epilogue, and workgroups that start together hit both phases together.
+    // Starting the second resident slot of every CU about half a tile late keeps the two slots out of phase for
+    // the rest of the launch (a slot runs its queue of tiles back to back), so one streams while the other
+    // multiplies.  Placement is not guaranteed -- only speed depends on it.
+    if (args.stagger_sleeps > 0 && (blockIdx.x >> 8) == 1)
+        for (int i = 0; i < args.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     // XCD-aware tile order inside the item: hardware deals workgroups round-robin over the 8 XCDs
     // (private 4 MiB L2 each) and item bases are multiples of 8, so local%8 names the XCD group.
     // Each group gets one contiguous chunk of the item's tile list (tiles that share A row panels /
