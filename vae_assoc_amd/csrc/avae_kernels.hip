@@ -538,20 +538,20 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
 #define AVAE_COMPUTE(buf, do_dma, dma_kt, dma_buf)                                                     \
     {                                                                                                  \
         const unsigned char* Sb = smem + (buf) * TileSmem<BM, BN, RING>::kStage;                       \
-        u32x4 a[MI], b[NI];                                                                            \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
-            a[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + sw0);            \
+        u32x4 a0[MI], b0[NI], a1[MI], b1[NI];      /* both K slabs' fragments: the second slab's LDS  */ \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)   /* latency hides behind the first slab's MFMAs */ \
+            a0[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + sw0);           \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
-            b[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + sw0);            \
+            b0[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + sw0);           \
         if (do_dma) AVAE_ABL_DMA(dma_kt, dma_buf)                                                      \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
-            _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a[i], b[j], acc[i][j]);             \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
-            a[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + (sw0 ^ 64));     \
+            a1[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + (sw0 ^ 64));    \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
-            b[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + (sw0 ^ 64));     \
+            b1[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + (sw0 ^ 64));    \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
-            _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a[i], b[j], acc[i][j]);             \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a0[i], b0[j], acc[i][j]);           \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a1[i], b1[j], acc[i][j]);           \
     }
 
     AVAE_STAMP(1)
