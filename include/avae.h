@@ -16,7 +16,7 @@
  *  - one handle = one model replica on one GPU; calls on one handle serialise on an internal
  *    mutex (the reference's callers use the session from a worker thread and the GUI thread,
  *    baxter_vae_assoc_writer.py:651-673); different handles are independent;
- *  - `stream` is a hipStream_t passed as void* (NULL = the library's own stream).  Work is
+ *  - `stream` is a hipStream_t passed as void* (NULL = the HIP null stream).  Work is
  *    enqueued asynchronously; a call only synchronises when it has to hand a host value back
  *    (a non-NULL `cost_host`, get/set of parameters, save/load);
  *  - matrices are row-major; an input batch of modality m is [rows, n_input_m] float32 with a
@@ -109,6 +109,14 @@ int avae_set_opt_state(avae_handle* h, const float* host_m, const float* host_v,
  *             (pre-update weights, as in the reference) after a stream synchronise. */
 int avae_train_step(avae_handle* h, const float* const* x_dev, const int32_t* x_ld,
                     const float* eps_dev, float* cost_host, void* stream);
+/* The inner batch loop of train() (vae_assoc.py:541-550 over DataSet.next_batch's consecutive slices,
+ * dataset.py:22-43) as ONE submission: exactly n_steps successive avae_train_step calls, step i on rows
+ * [i*batch_size, (i+1)*batch_size) of every x_dev[m] (row stride x_ld[m]) and of eps_dev (dense [.., n_z];
+ * NULL -> internal generator).  Steps are replayed eight to a hipGraph, so the host is out of the loop and
+ * the per-replay boundary is paid once per eight steps.  cost_host (optional) receives the LAST step's cost;
+ * every step's cost is in avae_cost_history. */
+int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev, const int32_t* x_ld,
+                     const float* eps_dev, float* cost_host, void* stream);
 /* The same step cut at the data-parallel seam: backward leaves the local gradient (internal
  * padded layout, pads zero) and, in the last float, the local cost in one contiguous device
  * buffer -- SUM-all-reduce that buffer across replicas, then apply. */
@@ -140,10 +148,11 @@ int avae_load(avae_handle* h, const char* path);
 
 /* Introspection used by bench.py / tests. */
 int avae_synchronize(avae_handle* h);
-/* Average device time (ms) of the kernels of one class over the calls since the last reset,
- * measured with hipEvents on the stream the kernels were launched on.  Only recorded while
- * timing is enabled (it forces eager launches instead of graph replay).  Values are raw brackets
- * (they include the dispatch latency); "_null_kernel_bracket" is the same bracket around a null kernel. */
+/* Average device time (ms) of every launch of the step over the calls since the last reset,
+ * measured with hipEvents on the stream the kernels were launched on (hipExtLaunchKernel start/stop
+ * events: the dispatch's own begin and end, what rocprofv3 --kernel-trace reports).  Only recorded
+ * while timing is enabled (it forces eager launches instead of graph replay); "_null_kernel" is a
+ * one-store kernel timed the same way.  Report: one line "<name> <calls> <avg_ms> <min_ms>" per launch. */
 int avae_timing_enable(avae_handle* h, int32_t on);
 int avae_timing_report(avae_handle* h, char* buf, size_t buf_bytes);
 /* Copies a named internal fp32 tensor to the host (tests): "mulv<m>" [batch,2*n_z], "eps" [batch,n_z]. */

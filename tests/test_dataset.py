@@ -33,6 +33,25 @@ def test_tail_is_dropped_and_reshuffled_on_wrap():
     assert sorted(ds._data[:, 0]) == list(range(10))
 
 
+def test_next_batches_is_a_run_of_next_batch_calls():
+    """next_batches(B, k) = the next n <= k next_batch(B) results as one slice, same state afterwards."""
+    x = np.arange(53, dtype=float)[:, None]
+    np.random.seed(7)
+    a = dataset.DataSet(x.copy(), labels=x.copy() * 2)
+    singles = [a.next_batch(5) for _ in range(40)]
+    np.random.seed(7)
+    b = dataset.DataSet(x.copy(), labels=x.copy() * 2)
+    got, asked = 0, [3, 1, 100, 4, 2, 7, 100, 100, 100]
+    while got < 40:
+        d, l, n = b.next_batches(5, min(asked[got % len(asked)], 40 - got))
+        assert n >= 1 and d.shape[0] == 5 * n
+        for j in range(n):
+            assert np.array_equal(d[5 * j:5 * j + 5], singles[got + j][0]) and np.array_equal(l[5 * j:5 * j + 5], singles[got + j][1])
+        got += n
+    assert (a._index_in_epoch, a._epochs_completed) == (b._index_in_epoch, b._epochs_completed)
+    assert np.array_equal(a._data, b._data)
+
+
 def test_labels_travel_with_data():
     np.random.seed(3)
     x = np.arange(20, dtype=float).reshape(10, 2)

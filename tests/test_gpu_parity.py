@@ -261,6 +261,35 @@ def test_graph_replay_equals_eager(V):
     assert np.array_equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("given_eps", [False, True])
+def test_train_steps_equals_single_steps(V, given_eps):
+    """avae_train_steps (runs of 8 steps per graph replay, staging nodes re-pointed per replay while earlier
+    replays are still in flight) is exactly n successive avae_train_step calls: bitwise equal costs and weights."""
+    archs = [make_arch("image", 784, 64, 48, 8), make_arch("joint", 147, 40, 32, 8)]
+    rng = np.random.default_rng(9)
+    n, B = 21, 32                                          # 2 replays of 8 + 5 single steps
+    data = np.concatenate(synth_batch(rng, n * B, [784, 147], [True, False]), axis=1)
+    dev = torch.as_tensor(data).cuda()
+    X = [dev[:, :784], dev[:, 784:]]                       # column slices of one matrix: row stride 931
+    eps = torch.as_tensor(rng.standard_normal((n * B, 8)).astype(np.float32)).cuda() if given_eps else None
+    res = []
+    for many in (False, True):
+        m = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="relu", weights=[50, 1], assoc_lambda=8.0,
+                                          batch_size=B, compute_dtype="bf16", seed=4)
+        if many:
+            last = m.partial_fit_steps(X, n, eps)
+        else:
+            for i in range(n):
+                last = m.partial_fit([x[i * B:(i + 1) * B] for x in X], None if eps is None else eps[i * B:(i + 1) * B],
+                                     return_cost=i == n - 1)
+        res.append((last, m.cost_history(n).copy(), m.get_params()))
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1]) and len(set(res[0][1].tolist())) == n      # n different batches, n different costs
+    assert np.array_equal(res[0][2], res[1][2])
+    with pytest.raises(ValueError):
+        m.partial_fit_steps([x[:B] for x in X], 2)         # rows must be batch_size x n_steps
+
+
 # ----------------------------------------------------------------------------- inference surface
 def test_transform_generate_reconstruct_rows(V):
     archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
@@ -480,6 +509,11 @@ def test_train_loop_matches_oracle_loop(V):
                     e = eps_all[Fed._k]
                     Fed._k += 1
                     return super().partial_fit(X, e, return_cost)
+
+                def partial_fit_steps(self, X, n_steps, eps=None, return_cost=True):
+                    e = np.concatenate(eps_all[Fed._k:Fed._k + n_steps])
+                    Fed._k += n_steps
+                    return super().partial_fit_steps(X, n_steps, e, return_cost)
             orig = V.AssocVariationalAutoEncoder
             V.AssocVariationalAutoEncoder = Fed
             try:

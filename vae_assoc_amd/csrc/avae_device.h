@@ -171,6 +171,9 @@ void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStre
 // Diagnostic build only (-DAVAE_STAMPS): thread 0 of every block records s_memrealtime (100 MHz)
 // at kernel entry / after the item lookup / after the first staged tile / after the K loop / at
 // the end, plus s_memtime (shader clock) at entry and end.  No stamp executes in the product build.
+struct LaunchEvents { hipEvent_t start, stop; };
+extern thread_local LaunchEvents t_launch_events;   // armed by the host in timing mode, consumed by the next launch
+
 constexpr int kStampLaunches = 32, kStampBlocks = 1024, kStampWords = 8;
 
 // launchers implemented in avae_kernels.hip
@@ -179,6 +182,7 @@ void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int
                     DevState* st, hipStream_t s, unsigned long long* stamps = nullptr, int launch_id = 0);
 void launch_adam(int compute_dtype, const AdamArgs& a, int n_blocks, hipStream_t s);
 void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s);
+const void* prep_kernel(int compute_dtype);          // for hipGraphExecKernelNodeSetParams on the captured staging node
 void launch_fill(void* base, int elem_bytes, unsigned bits, long long start, long long stride, int count, hipStream_t s);
 
 }  // namespace avae

@@ -125,6 +125,9 @@ struct avae_handle {
     std::vector<Inf> inf_enc, inf_dec;
 
     hipGraphExec_t g_full = nullptr, g_bwd = nullptr, g_adam = nullptr, g_eval = nullptr;
+    hipGraphExec_t g_multi = nullptr;       // kMultiSteps whole steps (avae_train_steps)
+    hipGraph_t g_full_graph = nullptr, g_multi_graph = nullptr;   // templates, kept: their staging-kernel nodes are re-parameterised per replay
+    std::vector<hipGraphNode_t> g_full_prep, g_multi_prep;
 
     bool timing = false;
     bool debug_sync = false;
@@ -507,6 +510,8 @@ struct Builder {
     }
 };
 
+constexpr int kMultiSteps = 8;          // whole steps per replay of the multi-step graph
+
 inline bool is_gemm(int kind) { return kind <= K_WGRAD || kind == K_WGRAD_ADAM || kind == K_DGRAD_F32; }
 
 // Fixes the tile configuration of one launch and lays its items' tiles out back to back.
@@ -801,11 +806,14 @@ struct Timed {
         if (!on) return;
         id = tname_id(h, name);
         HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
-        HIP_OK(hipEventRecord(a, s));
+        t_launch_events = LaunchEvents{a, b};         // the launch inside this scope stamps them with its own begin/end
     }
     ~Timed() {
         if (!on) return;
-        (void)hipEventRecord(b, s);
+        if (t_launch_events.start) {                  // nothing was launched (empty segment): record an empty bracket
+            t_launch_events = LaunchEvents{nullptr, nullptr};
+            (void)hipEventRecord(a, s); (void)hipEventRecord(b, s);
+        }
         h->trecs.push_back(TimingRec{a, b, id});
     }
 };
@@ -855,8 +863,8 @@ void run_adam(avae_handle* h, int mode, hipStream_t s) {
 }
 
 // stages the caller's batch (and eps) into the internal compute-dtype buffers
-void run_prep_batch(avae_handle* h, const float* const* x, const int32_t* x_ld, const float* eps, int rows,
-                    unsigned long long salt, hipStream_t s) {
+PrepArgs make_prep_batch(avae_handle* h, const float* const* x, const int32_t* x_ld, const float* eps, int rows,
+                         unsigned long long salt) {
     PrepArgs a;
     std::memset(&a, 0, sizeof(a));
     int base = 0;
@@ -875,6 +883,12 @@ void run_prep_batch(avae_handle* h, const float* const* x, const int32_t* x_ld, 
     a.eps_src = eps; a.eps_dst = h->at<float>(h->off_eps); a.eps_rows = rows; a.nz = h->nz; a.eps_ld = h->ld_eps;
     a.eps_blocks = (rows * ((h->nz + 3) / 4) + kThreads - 1) / kThreads;
     a.row_offset = h->cfg.row_offset; a.seed = h->cfg.seed; a.st = h->state(); a.stream_salt = salt;
+    return a;
+}
+
+void run_prep_batch(avae_handle* h, const float* const* x, const int32_t* x_ld, const float* eps, int rows,
+                    unsigned long long salt, hipStream_t s) {
+    const PrepArgs a = make_prep_batch(h, x, x_ld, eps, rows, salt);
     Timed t(h, s, "prep");
     launch_prep(h->cfg.compute_dtype, a, s);
 }
@@ -911,6 +925,59 @@ hipGraphExec_t capture(avae_handle* h, const std::function<void(hipStream_t)>& b
     return ge;
 }
 
+// Same, for `reps` back-to-back copies of a step that starts with the input-staging kernel: keeps the template
+// graph and the staging node of every copy so the caller's pointers can be patched in before a replay
+// (hipGraphExecKernelNodeSetParams).  Stream capture of one stream gives a linear chain; the staging kernels are
+// every (chain length / reps)-th node of it.
+hipGraphExec_t capture_with_prep(avae_handle* h, int reps, const std::function<void(hipStream_t)>& body, hipGraph_t* graph_out,
+                                 std::vector<hipGraphNode_t>* prep_nodes) {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIP_OK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    try { for (int r = 0; r < reps; ++r) body(h->cap_stream); }
+    catch (...) { (void)hipStreamEndCapture(h->cap_stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
+    HIP_OK(hipStreamEndCapture(h->cap_stream, &g));
+    try {
+        size_t n_nodes = 0, n_root = 0;
+        HIP_OK(hipGraphGetNodes(g, nullptr, &n_nodes));
+        HIP_OK(hipGraphGetRootNodes(g, nullptr, &n_root));
+        if (n_root != 1 || n_nodes == 0 || n_nodes % reps != 0) throw Err("internal error: captured step is not a chain of equal steps");
+        const size_t per_step = n_nodes / reps;
+        hipGraphNode_t node = nullptr;
+        HIP_OK(hipGraphGetRootNodes(g, &node, &n_root));
+        prep_nodes->clear();
+        for (size_t i = 0; i < n_nodes; ++i) {
+            if (i % per_step == 0) {
+                hipGraphNodeType ty;
+                HIP_OK(hipGraphNodeGetType(node, &ty));
+                if (ty != hipGraphNodeTypeKernel) throw Err("internal error: captured step does not start with the staging kernel");
+                prep_nodes->push_back(node);
+            }
+            if (i + 1 < n_nodes) {
+                size_t n_dep = 0;
+                HIP_OK(hipGraphNodeGetDependentNodes(node, nullptr, &n_dep));
+                if (n_dep != 1) throw Err("internal error: captured step is not a linear chain");
+                HIP_OK(hipGraphNodeGetDependentNodes(node, &node, &n_dep));
+            }
+        }
+        HIP_OK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    } catch (...) { (void)hipGraphDestroy(g); throw; }
+    *graph_out = g;
+    return ge;
+}
+
+// Points one captured staging node at the caller's batch.
+void patch_prep(avae_handle* h, hipGraphExec_t ge, hipGraphNode_t node, const float* const* x, const int32_t* x_ld, const float* eps) {
+    PrepArgs a = make_prep_batch(h, x, x_ld, eps, h->B, 0x7261696eull);
+    void* kp[1] = {&a};
+    hipKernelNodeParams np;
+    std::memset(&np, 0, sizeof(np));
+    np.func = const_cast<void*>(prep_kernel(h->cfg.compute_dtype));
+    np.gridDim = dim3(a.total_tiles + a.eps_blocks); np.blockDim = dim3(kThreads);
+    np.sharedMemBytes = 0; np.kernelParams = kp; np.extra = nullptr;
+    HIP_OK(hipGraphExecKernelNodeSetParams(ge, node, &np));
+}
+
 void fill_ones(avae_handle* h, const Act& a, hipStream_t s) {
     if (!a.ones) return;
     const unsigned bits = h->es == 2 ? 0x3F80u : 0x3F800000u;
@@ -942,10 +1009,15 @@ void init_device(avae_handle* h) {
         h->timing = false;
         h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, h->bwd, cs); run_launches(h, h->wg_plain, cs); });
         h->g_adam = capture(h, [&](hipStream_t cs) { run_adam(h, 0, cs); });
-        h->g_full = capture(h, [&](hipStream_t cs) {
+        std::vector<const float*> x0(h->M, h->at<float>(h->mods[0].X32));    // placeholders, patched per step
+        auto one_step = [&](hipStream_t cs) {
+            run_prep_batch(h, x0.data(), nullptr, nullptr, h->B, 0x7261696eull, cs);
             run_launches(h, h->fwd, cs, 0); run_launches(h, h->bwd, cs, (int)h->fwd.size());
             run_launches(h, h->wg_adam, cs, (int)(h->fwd.size() + h->bwd.size()));
-        });
+        };
+        h->g_full = capture_with_prep(h, 1, one_step, &h->g_full_graph, &h->g_full_prep);
+        // avae_train_steps: kMultiSteps whole steps per replay (a replay boundary costs ~5 us of idle GPU on this stack)
+        h->g_multi = capture_with_prep(h, kMultiSteps, one_step, &h->g_multi_graph, &h->g_multi_prep);
         h->g_eval = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, std::vector<Launch>{h->cost_only}, cs); });
         h->timing = tsave;
     }
@@ -1055,7 +1127,8 @@ void avae_destroy(avae_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
-    for (hipGraphExec_t g : {h->g_full, h->g_bwd, h->g_adam, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
+    for (hipGraphExec_t g : {h->g_full, h->g_multi, h->g_bwd, h->g_adam, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
+    for (hipGraph_t g : {h->g_full_graph, h->g_multi_graph}) if (g) (void)hipGraphDestroy(g);
     for (TimingRec& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->own_ws && h->ws) (void)hipFree(h->ws);
@@ -1124,18 +1197,54 @@ int avae_step_apply(avae_handle* h, float* cost_host, void* stream) {
     });
 }
 
+// one single-replica step (Adam rides in the epilogue of the weight-gradient launches)
+void train_one(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, hipStream_t s) {
+    if (h->g_full && !h->timing) {      // the whole step, staging kernel included, is one graph replay
+        patch_prep(h, h->g_full, h->g_full_prep[0], x_dev, x_ld, eps_dev);
+        HIP_OK(hipGraphLaunch(h->g_full, s));
+        return;
+    }
+    run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, s);
+    run_launches(h, h->fwd, s); run_launches(h, h->bwd, s); run_launches(h, h->wg_adam, s);
+    if (h->timing) {      // floor of the measurement: a one-store kernel (partial slot 0 is rewritten every step anyway)
+        Timed t(h, s, "_null_kernel");
+        launch_fill(h->at<void>(h->off_partial), 4, 0u, 0, 1, 1, s);
+    }
+}
+
 int avae_train_step(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, float* cost_host, void* stream) {
     return guarded(h, [&] {
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, s);
-        // single replica: Adam rides in the epilogue of the weight-gradient launches
-        if (h->g_full && !h->timing) HIP_OK(hipGraphLaunch(h->g_full, s));
-        else {
-            run_launches(h, h->fwd, s); run_launches(h, h->bwd, s); run_launches(h, h->wg_adam, s);
-            if (h->timing) {      // calibration bracket for avae_timing_report (partial slot 0 is rewritten every step anyway)
-                Timed t(h, s, "_null_kernel_bracket");
-                launch_fill(h->at<void>(h->off_partial), 4, 0u, 0, 1, 1, s);
+        train_one(h, x_dev, x_ld, eps_dev, s);
+        fetch_cost(h, cost_host, true, s);
+    });
+}
+
+int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev,
+                     float* cost_host, void* stream) {
+    return guarded(h, [&] {
+        if (n_steps < 1) throw Err("avae_train_steps: n_steps must be >= 1");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        std::vector<const float*> x(h->M);
+        auto batch = [&](int i) {       // rows [i*B, (i+1)*B) of every modality and of eps
+            for (int m = 0; m < h->M; ++m) {
+                const size_t ld = (x_ld && x_ld[m] > 0) ? (size_t)x_ld[m] : (size_t)h->mods[m].n_in;
+                x[m] = x_dev[m] + (size_t)i * h->B * ld;
             }
+            return eps_dev ? eps_dev + (size_t)i * h->B * h->nz : nullptr;
+        };
+        int i = 0;
+        if (h->g_multi && !h->timing)
+            for (; i + kMultiSteps <= n_steps; i += kMultiSteps) {
+                for (int j = 0; j < kMultiSteps; ++j) {
+                    const float* e = batch(i + j);
+                    patch_prep(h, h->g_multi, h->g_multi_prep[j], x.data(), x_ld, e);
+                }
+                HIP_OK(hipGraphLaunch(h->g_multi, s));
+            }
+        for (; i < n_steps; ++i) {
+            const float* e = batch(i);
+            train_one(h, x.data(), x_ld, e, s);
         }
         fetch_cost(h, cost_host, true, s);
     });
@@ -1314,10 +1423,9 @@ int avae_timing_enable(avae_handle* h, int32_t on) {
 int avae_timing_report(avae_handle* h, char* buf, size_t buf_bytes) {
     return guarded(h, [&] {
         HIP_OK(hipDeviceSynchronize());
-        // While timing is on every step also brackets a null kernel (one 4-byte store) on the same, busy stream:
-        // it is reported as "_null_kernel_bracket" so a reader can see what the bracket itself costs (the event
-        // packets and the dispatch sit INSIDE every interval; rocprofv3 gives the null kernel 1.5 us).  Nothing is
-        // subtracted: the reported averages are raw brackets, i.e. upper bounds of the kernel durations.
+        // Each interval is the dispatch's own begin -> end (hipExtLaunchKernel events), the times rocprofv3
+        // --kernel-trace reports.  While timing is on every step also times a null kernel (one 4-byte store),
+        // reported as "_null_kernel": the floor of what one launch can measure.  Nothing is subtracted.
         const double cal_ms = 0.0;
         std::vector<double> sum(h->tnames.size(), 0.0), mn(h->tnames.size(), 1e30);
         std::vector<long> cnt(h->tnames.size(), 0);

@@ -20,6 +20,7 @@
 // Reference maths: /root/reference/vae_assoc.py:163-222 (encoder), :243-304 (decoder),
 // :306-371 (losses), :373-374 (Adam); restated for CPU in oracle/vae_assoc_oracle.py.
 #include "avae_device.h"
+#include <hip/hip_ext.h>
 #include "../../include/avae.h"
 
 namespace avae {
@@ -736,6 +737,21 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
     AVAE_STAMP_FLUSH()
 }
 
+// Timing mode (avae_timing_enable): the host arms one (start, stop) event pair per launch; the launch then
+// goes through hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin/end timestamps --
+// the same signal times rocprofv3 --kernel-trace reports -- instead of bracketing it with marker packets.
+thread_local LaunchEvents t_launch_events = {nullptr, nullptr};
+
+#define AVAE_LAUNCH(kernel, grid, block, lds, stream, ...)                                                   \
+    do {                                                                                                     \
+        if (t_launch_events.start) {                                                                         \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, t_launch_events.start, t_launch_events.stop, 0, __VA_ARGS__); \
+            t_launch_events = LaunchEvents{nullptr, nullptr};                                                \
+        } else {                                                                                             \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                               \
+        }                                                                                                    \
+    } while (0)
+
 template <typename K> static void set_max_lds(K kernel) {
     // > 64 KiB of dynamic LDS has to be opted into once per kernel
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -751,11 +767,11 @@ void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int
     (void)once;
     dim3 grid(n_blocks), block(kThreads);
     if (compute_dtype == AVAE_BF16) {
-        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<__bf16, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-        else hipLaunchKernelGGL((k_grouped<__bf16, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+        if (tile_cfg == 0) AVAE_LAUNCH((k_grouped<__bf16, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+        else AVAE_LAUNCH((k_grouped<__bf16, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
     } else {
-        if (tile_cfg == 0) hipLaunchKernelGGL((k_grouped<float, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-        else hipLaunchKernelGGL((k_grouped<float, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+        if (tile_cfg == 0) AVAE_LAUNCH((k_grouped<float, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+        else AVAE_LAUNCH((k_grouped<float, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
     }
 }
 
@@ -831,8 +847,8 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
 }
 
 void launch_adam(int compute_dtype, const AdamArgs& a, int n_blocks, hipStream_t s) {
-    if (compute_dtype == AVAE_BF16) hipLaunchKernelGGL((k_adam<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((k_adam<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_adam<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else AVAE_LAUNCH((k_adam<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
 // ------------------------------------------------------------------ input staging + eps
@@ -925,11 +941,15 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
     }
 }
 
+const void* prep_kernel(int compute_dtype) {
+    return compute_dtype == AVAE_BF16 ? reinterpret_cast<const void*>(k_prep<__bf16>) : reinterpret_cast<const void*>(k_prep<float>);
+}
+
 void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s) {
     const int n_blocks = a.total_tiles + a.eps_blocks;
     if (n_blocks <= 0) return;
-    if (compute_dtype == AVAE_BF16) hipLaunchKernelGGL((k_prep<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((k_prep<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_prep<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else AVAE_LAUNCH((k_prep<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
 // ------------------------------------------------------------------ conv branch: im2col / col2im
@@ -1069,13 +1089,13 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
 
 void launch_gather(int compute_dtype, const GatherArgs& a, int n_blocks, hipStream_t s) {
     if (n_blocks <= 0) return;
-    if (compute_dtype == AVAE_BF16) hipLaunchKernelGGL((k_gather<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((k_gather<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_gather<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else AVAE_LAUNCH((k_gather<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStream_t s) {
     if (n_blocks <= 0) return;
-    if (compute_dtype == AVAE_BF16) hipLaunchKernelGGL((k_col2im<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((k_col2im<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_col2im<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else AVAE_LAUNCH((k_col2im<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
 // ------------------------------------------------------------------ strided fill (constant-1 columns)
@@ -1089,7 +1109,7 @@ __global__ void k_fill(unsigned char* base, int elem_bytes, unsigned bits, long 
 
 void launch_fill(void* base, int elem_bytes, unsigned bits, long long start, long long stride, int count, hipStream_t s) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_fill, dim3((count + 255) / 256), dim3(256), 0, s, reinterpret_cast<unsigned char*>(base),
+    AVAE_LAUNCH(k_fill, dim3((count + 255) / 256), dim3(256), 0, s, reinterpret_cast<unsigned char*>(base),
                        elem_bytes, bits, start, stride, count);
 }
 

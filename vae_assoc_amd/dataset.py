@@ -50,6 +50,18 @@ class DataSet(object):
             return self._data[start:end], self._labels[start:end]
         return self._data[start:end], None
 
+    def next_batches(self, batch_size, max_batches):
+        """``n <= max_batches`` successive ``next_batch`` results as ONE contiguous slice of ``n*batch_size``
+        rows: the first call may reshuffle exactly as ``next_batch`` does, the run then extends as far as
+        the slices stay consecutive (up to the next wrap).  Returns ``(data, labels, n)``; the state
+        afterwards is what ``n`` ``next_batch`` calls leave behind."""
+        self.next_batch(batch_size)
+        start = self._index_in_epoch - batch_size
+        n = 1 + max(0, min(int(max_batches) - 1, (self._num_examples - self._index_in_epoch) // batch_size))
+        self._index_in_epoch = start + n * batch_size
+        end = self._index_in_epoch
+        return self._data[start:end], (self._labels[start:end] if self._labels is not None else None), n
+
 
 def construct_datasets(data, labels=None, shuffle=True, validation_ratio=.1, test_ratio=.1):
     data_sets = DataSets()

@@ -242,23 +242,24 @@ class AssocVariationalAutoEncoder(object):
             t = t.contiguous()
         return t, was_np
 
-    def _batch_args(self, X, eps):
+    def _batch_args(self, X, eps, n_steps=1):
         assert len(X) == len(self.network_architectures)
         ts = []
+        rows = self.batch_size * n_steps
         for x, na in zip(X, self.network_architectures):
             t, _ = self._dev(x, int(na["n_input"]))
-            if t.shape[0] != self.batch_size:
+            if t.shape[0] != rows:
                 # the reference's eps has static shape (batch_size, n_z): every path through z
                 # needs exactly batch_size rows (vae_assoc.py:90)
-                raise ValueError("expected %d rows (batch_size), got %d" % (self.batch_size, t.shape[0]))
+                raise ValueError("expected %d rows (batch_size%s), got %d" % (rows, " x n_steps" if n_steps > 1 else "", t.shape[0]))
             ts.append(t)
         ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
         lds = (C.c_int32 * len(ts))(*[t.stride(0) if t.shape[0] > 1 else t.shape[1] for t in ts])
         e = None
         if eps is not None:
             e, _ = self._dev(eps, self.n_z)
-            if e.shape[0] != self.batch_size:
-                raise ValueError("eps must be [batch_size, n_z]")
+            if e.shape[0] != rows:
+                raise ValueError("eps must be [batch_size%s, n_z]" % (" x n_steps" if n_steps > 1 else ""))
             e = e.contiguous()
         return ts, ptrs, lds, e
 
@@ -325,6 +326,25 @@ class AssocVariationalAutoEncoder(object):
         _capi.check(self._h, self._L.avae_train_step(self._h, ptrs, lds, e.data_ptr() if e is not None else None,
                                                      C.byref(cost) if return_cost else None, self._stream()),
                     "avae_train_step")
+        return cost.value if return_cost else None
+
+    def partial_fit_steps(self, X, n_steps, eps=None, return_cost=True):
+        """``n_steps`` successive ``partial_fit`` calls in one submission: step i trains on rows
+        [i*batch_size, (i+1)*batch_size) of every X[m] (and of ``eps``) -- what the reference's inner
+        loop does with ``DataSet.next_batch``'s consecutive slices (vae_assoc.py:541-550).  Returns the
+        last step's cost; every step's cost is in ``cost_history``."""
+        n_steps = int(n_steps)
+        if self._sync is not None and self._sync.world_size > 1:      # the all-reduce sits between backward and Adam
+            B, cost = self.batch_size, None
+            for i in range(n_steps):
+                cost = self.partial_fit([x[i * B:(i + 1) * B] for x in X], None if eps is None else eps[i * B:(i + 1) * B],
+                                        return_cost and i == n_steps - 1)
+            return cost
+        ts, ptrs, lds, e = self._batch_args(X, eps, n_steps)
+        cost = C.c_float(0.0)
+        _capi.check(self._h, self._L.avae_train_steps(self._h, n_steps, ptrs, lds, e.data_ptr() if e is not None else None,
+                                                      C.byref(cost) if return_cost else None, self._stream()),
+                    "avae_train_steps")
         return cost.value if return_cost else None
 
     def evaluate_cost(self, X, eps=None):
@@ -442,9 +462,10 @@ def train(data_sets, network_architectures, binary=True, weights=1.0, assoc_lamb
     split of the [N, sum n_input] matrix (:510,:543), optional validation early stop (:520-537),
     ``avg_cost_hist`` = running within-epoch sum appended per batch (:576-577).
 
-    The batch matrix is uploaded once per step and split into modalities on the device by
-    pointer offset + row stride (no per-modality copies); per-step costs are read back once per
-    epoch from the device-side history, so the hot loop never synchronises."""
+    Runs of consecutive ``next_batch`` slices (everything between two reshuffles) are handed over as one
+    matrix and trained in one submission (``partial_fit_steps``); the matrix is split into modalities on
+    the device by pointer offset + row stride (no per-modality copies); per-step costs are read back once
+    per epoch from the device-side history, so the hot loop never synchronises."""
     vae_assoc = AssocVariationalAutoEncoder(network_architectures, binary, transfer_fct="relu", weights=weights,
                                             assoc_lambda=assoc_lambda, learning_rate=learning_rate,
                                             batch_size=batch_size, **model_kwargs)
@@ -481,9 +502,16 @@ def train(data_sets, network_architectures, binary=True, weights=1.0, assoc_lamb
         done = 0
         while done < total_batch:
             chunk = min(hist_cap, total_batch - done)
-            for i in range(chunk):
-                batch_xs, _ = data_sets.train.next_batch(batch_size)
-                vae_assoc.partial_fit(seg(batch_xs), return_cost=False)
+            got = 0
+            while got < chunk:
+                if hasattr(data_sets.train, "next_batches"):     # a run of consecutive slices = one submission
+                    batch_xs, _, n = data_sets.train.next_batches(batch_size, chunk - got)
+                    vae_assoc.partial_fit_steps(seg(batch_xs), n, return_cost=False)
+                else:                                             # a reference-style DataSet object
+                    batch_xs, _ = data_sets.train.next_batch(batch_size)
+                    vae_assoc.partial_fit(seg(batch_xs), return_cost=False)
+                    n = 1
+                got += n
             for cost in vae_assoc.cost_history(chunk):
                 avg_cost += float(cost) / n_samples * batch_size
                 avg_cost_hist.append(avg_cost)
