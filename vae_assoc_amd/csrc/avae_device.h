@@ -68,11 +68,14 @@ struct WorkItem {
 // segment together with the first block index of every item: a workgroup finds and reads its item
 // without a chain of dependent loads from HBM, and no device-side table has to be kept in sync.
 constexpr int kMaxItemsPerLaunch = 12;
+// Grid: x = tile slot inside an item (a multiple of 8, at least the largest item's tile count), y = item.
+// A workgroup knows its item from blockIdx.y alone, so its WorkItem is ONE scalar-load round trip into the
+// kernel-argument segment away; workgroups beyond their item's last tile exit at once.
 struct LaunchArgs {
     int n_items;
-    int base[kMaxItemsPerLaunch];
+    int grid_x;
     int stagger_sleeps;                     // > 0: workgroups 256..511 (the second resident slot of every CU) start that many
-    int pad[2];                             //      s_sleep(127) periods late, see k_grouped
+    int pad;                                //      s_sleep(127) periods late, see k_grouped
     WorkItem items[kMaxItemsPerLaunch];
 };
 
@@ -178,7 +181,7 @@ constexpr int kStampLaunches = 32, kStampBlocks = 1024, kStampWords = 8;
 
 // launchers implemented in avae_kernels.hip
 int tile_lds_bytes(int tile_cfg, bool two_c_tiles);
-void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int n_blocks, int lds_bytes,
+void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
                     DevState* st, hipStream_t s, unsigned long long* stamps = nullptr, int launch_id = 0);
 void launch_adam(int compute_dtype, const AdamArgs& a, int n_blocks, hipStream_t s);
 void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s);

@@ -88,6 +88,7 @@ struct Launch {
     std::string name;
     int type = 0;          // 0: grouped GEMM kernel, 1: k_gather (im2col), 2: k_col2im
     int cfg = 0, first = 0, count = 0, blocks = 0, lds = 0;
+    int grid_x = 1, grid_y = 1;   // grouped kernel: tile slot x item
     LaunchArgs args{};
     GatherArgs ga{};
     Col2imArgs ca{};
@@ -528,28 +529,27 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
     }
     L.cfg = (need128 || (tiles128 >= 192 && !narrow)) ? 1 : 0;
     const int T = L.cfg ? 128 : 64;
-    int base = 0;
+    int max_tiles = 1;
     for (int i = first; i < first + count; ++i) {
         WorkItem& w = items[i];
-        base = (base + 7) & ~7;          // item bases are multiples of 8 (the kernel's XCD-aware tile order needs it)
-        w.tile_base = base;
+        w.tile_base = 0;
         if (is_gemm(w.kind)) {
             w.tiles_m = (w.M + T - 1) / T;
             w.tiles_n = (w.N + T - 1) / T;
             if ((w.kind == K_FWD_HEAD || w.kind == K_DGRAD_LATENT) && w.tiles_n != 1) throw Err("internal error: head tile");
             if (w.kind == K_FWD_OUT_LOSS) { w.slot_base = *next_slot; *next_slot += w.tiles_m * w.tiles_n; }
-            base += w.tiles_m * w.tiles_n;
         } else if (w.kind == K_LATENT) {
             w.tiles_m = (w.M + kLatentRows - 1) / kLatentRows; w.tiles_n = 1;
             w.slot_base = *next_slot; *next_slot += w.tiles_m;
-            base += w.tiles_m;
         } else {   // K_COST
             w.tiles_m = w.tiles_n = 1;
             w.n_slots = *next_slot;
-            base += 1;
         }
+        max_tiles = std::max(max_tiles, w.tiles_m * w.tiles_n);
     }
-    L.blocks = base;
+    // grid: x = tile slot (multiple of 8: the kernel's XCD-aware tile order needs it), y = item
+    L.grid_x = (max_tiles + 7) & ~7; L.grid_y = count;
+    L.blocks = L.grid_x * L.grid_y;
     {
         bool two = false;
         for (int i = first; i < first + count; ++i) two = two || items[i].kind == K_FWD_HEAD || items[i].kind == K_DGRAD_LATENT;
@@ -567,7 +567,8 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         }
         if (all_wga) L.args.stagger_sleeps = std::max(1, nk_max / 6);     // ~3.4 us per sleep period: about half of a tile's K loop
     }
-    for (int i = 0; i < count; ++i) { L.args.base[i] = items[first + i].tile_base; L.args.items[i] = items[first + i]; }
+    L.args.grid_x = L.grid_x;
+    for (int i = 0; i < count; ++i) L.args.items[i] = items[first + i];
     if (*next_slot > h->n_partial) throw Err("internal error: cost partial slots overflow");
     return L;
 }
@@ -828,7 +829,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
 #endif
         if (L.type == 1) launch_gather(h->cfg.compute_dtype, L.ga, L.blocks, s);
         else if (L.type == 2) launch_col2im(h->cfg.compute_dtype, L.ca, L.blocks, s);
-        else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.blocks, L.lds, h->state(), s, stamps, stamp_base + k);
+        else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to
             std::fprintf(stderr, "[avae] launch %s type=%d cfg=%d items=%d blocks=%d\n", L.name.c_str(), L.type, L.cfg, L.count, L.blocks);
             for (int i = 0; i < L.args.n_items && L.type == 0; ++i)

@@ -439,35 +439,31 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
 #ifdef AVAE_STAMPS
     unsigned long long sv[kStampWords] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define AVAE_STAMP(i) { __builtin_amdgcn_sched_barrier(0); sv[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
-#define AVAE_STAMP_FLUSH() { if (stamps && threadIdx.x == 0 && launch_id < kStampLaunches && blockIdx.x < kStampBlocks) { \
-        for (int i_ = 0; i_ < kStampWords; ++i_) stamps[((size_t)launch_id * kStampBlocks + blockIdx.x) * kStampWords + i_] = sv[i_]; } }
+#define AVAE_STAMP_FLUSH() { const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x;                                        \
+    if (stamps && threadIdx.x == 0 && launch_id < kStampLaunches && lin_ < (unsigned)kStampBlocks) {                            \
+        for (int i_ = 0; i_ < kStampWords; ++i_) stamps[((size_t)launch_id * kStampBlocks + lin_) * kStampWords + i_] = sv[i_]; } }
     AVAE_STAMP(0)
 #else
 #define AVAE_STAMP(i)
 #define AVAE_STAMP_FLUSH()
 #endif
 
-    const int bid = blockIdx.x;
-    int it = 0;
-#pragma unroll
-    for (int i = 1; i < kMaxItemsPerLaunch; ++i)
-        if (i < args.n_items && bid >= args.base[i]) it = i;     // bases ascend; everything is a kernel argument
-    const WorkItem w = args.items[it];                            // one burst of scalar loads from the kernarg segment
+    const WorkItem w = args.items[blockIdx.y];                    // one burst of scalar loads from the kernarg segment
     // Multi-round launches of long weight-gradient tiles (two resident workgroups per CU): the MFMA-bound K loop
     // is followed by an HBM-bound Adam epilogue, and workgroups that start together hit both phases together.
     // Starting the second resident slot of every CU about half a tile late keeps the two slots out of phase for
     // the rest of the launch (a slot runs its queue of tiles back to back), so one streams while the other
     // multiplies.  Placement is not guaranteed -- only speed depends on it.
-    if (args.stagger_sleeps > 0 && (blockIdx.x >> 8) == 1)
+    if (args.stagger_sleeps > 0 && ((blockIdx.y * args.grid_x + blockIdx.x) >> 8) == 1)
         for (int i = 0; i < args.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     // XCD-aware tile order inside the item: hardware deals workgroups round-robin over the 8 XCDs
-    // (private 4 MiB L2 each) and item bases are multiples of 8, so local%8 names the XCD group.
+    // (private 4 MiB L2 each) in linear order y*grid_x + x, and grid_x is a multiple of 8, so x%8 names the XCD group.
     // Each group gets one contiguous chunk of the item's tile list (tiles that share A row panels /
     // B column panels meet in one L2); every item is still spread over all XCDs, which keeps heavy
     // and light items balanced.  Bijective for any tile count; only speed depends on it.
     int t;
     {
-        const int local = bid - w.tile_base, nt = w.tiles_m * w.tiles_n;
+        const int local = blockIdx.x, nt = w.tiles_m * w.tiles_n;
         const int q = nt >> 3, r = nt & 7, xcd = local & 7, j = local >> 3;
         if (j >= q + (xcd < r ? 1 : 0)) return;                   // padding block behind the item's last tile
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
@@ -757,7 +753,7 @@ template <typename K> static void set_max_lds(K kernel) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int n_blocks, int lds_bytes,
+void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
                     DevState* st, hipStream_t s, unsigned long long* stamps, int launch_id) {
     static const bool once = [] {
         set_max_lds(k_grouped<__bf16, 64, 64, 4>); set_max_lds(k_grouped<__bf16, 128, 128, 2>);
@@ -765,7 +761,7 @@ void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int
         return true;
     }();
     (void)once;
-    dim3 grid(n_blocks), block(kThreads);
+    dim3 grid(grid_x, grid_y), block(kThreads);
     if (compute_dtype == AVAE_BF16) {
         if (tile_cfg == 0) AVAE_LAUNCH((k_grouped<__bf16, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
         else AVAE_LAUNCH((k_grouped<__bf16, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
