@@ -246,6 +246,14 @@ def test_large_tile_path(V, dtype):
     check_step_parity(V, archs, [True, False], [5.0, 1.0], 0.5, "softplus", 2048, dtype, steps=2)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_wide_tile_path(V, dtype):
+    """Launches with >= 192 tiles of 256x128 run the 8-wave kernel (hidden-layer forward / dgrad and plain weight
+    gradients of the big nets, unfused Adam): parity at that size, softplus for the reason given above."""
+    archs = [make_arch("a", 784, 0, 0, 16, n_hidden=[1024, 768]), make_arch("b", 147, 0, 0, 16, n_hidden=[1024, 768])]
+    check_step_parity(V, archs, [True, False], [5.0, 1.0], 0.5, "softplus", 4096, dtype, steps=1)
+
+
 def test_graph_replay_equals_eager(V):
     archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
     rng = np.random.default_rng(3)

@@ -11,7 +11,7 @@ namespace avae {
 constexpr int kMaxMod = 4;
 constexpr int kThreads = 256;          // 4 wavefronts of 64
 constexpr int kTileBytesK = 128;       // bytes of K per staged tile row: 64 bf16 or 32 f32
-constexpr int kRowAlign = 128;         // row counts of GEMM operands are padded to this (largest tile)
+constexpr int kRowAlign = 256;         // row counts of GEMM operands are padded to this (largest tile)
 constexpr int kLatentRows = 16;        // rows per latent work-item tile (many small blocks: the item is latency-bound)
 constexpr int kCostHist = 4096;        // ring of per-step costs kept on the device
 

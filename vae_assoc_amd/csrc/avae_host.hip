@@ -529,13 +529,25 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         if (is_gemm(w.kind) && (w.N <= 64 || w.M <= 64)) narrow = true;      // a 128-wide tile would be mostly padding
     }
     L.cfg = (need128 || (tiles128 >= 192 && !narrow)) ? 1 : 0;
-    const int T = L.cfg ? 128 : 64;
+    {   // 256x128 tiles, 8 waves, one workgroup per CU: a third more flops per operand byte pulled from L2 into LDS,
+        // and that fill rate (~60-70 GB/s per CU) is what bounds the 128x128 loop.  Plain single-C-tile kinds on big
+        // problems only.  (AVAE_NO_256=1 keeps the 128x128 kernel: A/B measurements.)
+        bool plain = std::getenv("AVAE_NO_256") == nullptr;
+        long tiles256 = 0;
+        for (int i = first; i < first + count; ++i) {
+            const WorkItem& w = items[i];
+            plain = plain && (w.kind == K_FWD_HIDDEN || w.kind == K_DGRAD_HIDDEN || w.kind == K_WGRAD);
+            tiles256 += (long)((w.M + 255) / 256) * ((w.N + 127) / 128);
+        }
+        if (L.cfg == 1 && plain && tiles256 >= 192) L.cfg = 2;
+    }
+    const int T = L.cfg ? 128 : 64, TM = L.cfg == 2 ? 256 : T;
     int max_tiles = 1;
     for (int i = first; i < first + count; ++i) {
         WorkItem& w = items[i];
         w.tile_base = 0;
         if (is_gemm(w.kind)) {
-            w.tiles_m = (w.M + T - 1) / T;
+            w.tiles_m = (w.M + TM - 1) / TM;
             w.tiles_n = (w.N + T - 1) / T;
             if ((w.kind == K_FWD_HEAD || w.kind == K_DGRAD_LATENT) && w.tiles_n != 1) throw Err("internal error: head tile");
             if (w.kind == K_FWD_OUT_LOSS) { w.slot_base = *next_slot; *next_slot += w.tiles_m * w.tiles_n; }

@@ -186,11 +186,11 @@ template <int LDC> __device__ __forceinline__ int cs_idx(int r, int c) { return 
 // load->wait->store chains): A) unconditional loads (addresses clamped into the allocation),
 // B) the fused element maths, C) predicated stores.  Partial quads are stored element-wise so the
 // zero padding and the constant-1 column are never touched.
-template <typename OT, typename AT, bool HAS_AUX, bool WRITEBACK, int BM, int BN, typename Op>
+template <typename OT, typename AT, bool HAS_AUX, bool WRITEBACK, int BM, int BN, int NT = kThreads, typename Op>
 __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT* aux, int ldx,
                                           int M, int N, int m0, int n0, Op op) {
     constexpr int VW = Vec16<OT>::VW;                     // elements per 16-byte store
-    constexpr int LDC = BN + 4, QC = BN / VW, NQT = BM * QC / kThreads;
+    constexpr int LDC = BN + 4, QC = BN / VW, NQT = BM * QC / NT;
     constexpr int NQ = NQT < 32 / VW ? NQT : 32 / VW;     // groups handled together: <= 32 elements per array in flight
     static_assert(NQT % NQ == 0, "tile / thread mapping");
     const int tid = threadIdx.x;
@@ -198,7 +198,7 @@ __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT*
         float c[NQ][VW], a[NQ][VW];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
+            const int idx = tid + (q0 + q) * NT, row = idx / QC, c0 = (idx - row * QC) * VW;
 #pragma unroll
             for (int h = 0; h < VW / 4; ++h) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + cs_idx<LDC>(row, c0 + 4 * h));
@@ -214,7 +214,7 @@ __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT*
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
+            const int idx = tid + (q0 + q) * NT, row = idx / QC, c0 = (idx - row * QC) * VW;
             const bool rok = m0 + row < M;
 #pragma unroll
             for (int e = 0; e < VW; ++e) c[q][e] = op(c[q][e], a[q][e], rok && (n0 + c0 + e < N));
@@ -226,30 +226,30 @@ __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT*
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * VW;
+            const int idx = tid + (q0 + q) * NT, row = idx / QC, c0 = (idx - row * QC) * VW;
             const int grow = m0 + row, gcol = n0 + c0;
             if (grow < M && gcol < N) store_vec<OT, VW>(out + (size_t)grow * ld0 + gcol, c[q], N - gcol);
         }
     }
 }
 
-template <typename OT, int BM, int BN>
+template <typename OT, int BM, int BN, int NT = kThreads>
 __device__ __forceinline__ void transposed_store(const float* Cs, OT* out, int ld, int M, int N, int m0, int n0) {
     constexpr int VW = Vec16<OT>::VW;
-    constexpr int LDC = BN + 4, QR = BM / VW, NQT = BN * QR / kThreads;
+    constexpr int LDC = BN + 4, QR = BM / VW, NQT = BN * QR / NT;
     constexpr int NQ = NQT < 32 / VW ? NQT : 32 / VW;
     static_assert(NQT % NQ == 0, "tile / thread mapping");
     for (int q0 = 0; q0 < NQT; q0 += NQ) {
         float v[NQ][VW];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int idx = threadIdx.x + (q0 + q) * kThreads, col = idx / QR, r0 = (idx - col * QR) * VW;
+            const int idx = threadIdx.x + (q0 + q) * NT, col = idx / QR, r0 = (idx - col * QR) * VW;
 #pragma unroll
             for (int e = 0; e < VW; ++e) v[q][e] = Cs[cs_idx<LDC>(r0 + e, col)];
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int idx = threadIdx.x + (q0 + q) * kThreads, col = idx / QR, r0 = (idx - col * QR) * VW;
+            const int idx = threadIdx.x + (q0 + q) * NT, col = idx / QR, r0 = (idx - col * QR) * VW;
             const int gcol = n0 + col, grow = m0 + r0;
             if (gcol < N && grow < M) store_vec<OT, VW>(out + (size_t)gcol * ld + grow, v[q], M - grow);
         }
@@ -423,16 +423,18 @@ template <int BM, int BN, int RING> struct TileSmem {
     static constexpr int kStages = RING * kStage;
     static constexpr int kC = BM * (BN + 4) * 4;               // one fp32 accumulator tile
 };
+// tile_cfg: 0 = 64x64 tile, 4-stage ring; 1 = 128x128 tile, 2-stage ring, two workgroups per CU;
+//           2 = 256x128 tile, 3-stage ring, one workgroup per CU (big single-C-tile kinds only)
 int tile_lds_bytes(int tile_cfg, bool two_c_tiles) {
-    const int stages = tile_cfg ? TileSmem<128, 128, 2>::kStages : TileSmem<64, 64, 4>::kStages;
-    const int c = (tile_cfg ? TileSmem<128, 128, 2>::kC : TileSmem<64, 64, 4>::kC) * (two_c_tiles ? 2 : 1);
+    const int stages = tile_cfg == 2 ? TileSmem<256, 128, 3>::kStages : tile_cfg == 1 ? TileSmem<128, 128, 2>::kStages : TileSmem<64, 64, 4>::kStages;
+    const int c = (tile_cfg == 2 ? TileSmem<256, 128, 3>::kC : tile_cfg == 1 ? TileSmem<128, 128, 2>::kC : TileSmem<64, 64, 4>::kC) * (two_c_tiles ? 2 : 1);
     return (stages > c ? stages : c) + 64;                     // + block-reduction scratch
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char avae_dyn_smem[];
 
-template <typename CT, int BM, int BN, int RING>
-__global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const LaunchArgs args, DevState* st, int lds_bytes,
+template <typename CT, int BM, int BN, int RING, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const LaunchArgs args, DevState* st, int lds_bytes,
                                                       unsigned long long* stamps, int launch_id) {
     unsigned char* smem = avae_dyn_smem;
     float* red = reinterpret_cast<float*>(smem + lds_bytes - 64);
@@ -446,6 +448,17 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
 #else
 #define AVAE_STAMP(i)
 #define AVAE_STAMP_FLUSH()
+#endif
+#if defined(AVAE_STAMPS) && defined(AVAE_LOOPSTAMPS)
+    // diagnostic: shader-clock cycles per section of the K loop, summed over the K tiles of this workgroup (wave 0)
+    unsigned long long la[6] = {0, 0, 0, 0, 0, 0}, lt = 0;
+#define AVAE_LT0() { __builtin_amdgcn_sched_barrier(0); lt = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#define AVAE_LT(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_readcyclecounter(); la[i] += n_ - lt; lt = n_; __builtin_amdgcn_sched_barrier(0); }
+#define AVAE_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define AVAE_LT0()
+#define AVAE_LT(i)
+#define AVAE_LGKM0()
 #endif
 
     const WorkItem w = args.items[blockIdx.y];                    // one burst of scalar loads from the kernarg segment
@@ -468,12 +481,14 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
         if (j >= q + (xcd < r ? 1 : 0)) return;                   // padding block behind the item's last tile
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    if (w.kind == K_LATENT) { latent_item(w, t, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
-    if (w.kind == K_COST) { cost_item(w, st, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
+    constexpr int NT = NW * 64;
+    if constexpr (NW == 4) {
+        if (w.kind == K_LATENT) { latent_item(w, t, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
+        if (w.kind == K_COST) { cost_item(w, st, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
+    }
 
-    constexpr int WM = BM / 2, WN = BN / 2;       // per-wave sub-tile (2x2 waves)
+    constexpr int WM = BM / (NW / 2), WN = BN / 2;   // per-wave sub-tile: waves are arranged (NW/2) x 2
     constexpr int MI = WM / 16, NI = WN / 16;
-    constexpr int NCA = BM * 8 / kThreads, NCB = BN * 8 / kThreads;   // 16-B chunks per thread per tile
     constexpr int LDC = BN + 4;
     constexpr int ES = (int)sizeof(CT);
 
@@ -503,12 +518,12 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
     typedef const __attribute__((address_space(1))) void* gp_t;
     typedef __attribute__((address_space(3))) void* lp_t;
     constexpr int R8 = (BM + BN) / 8;          // wave-instructions per tile
-    constexpr int NCH = R8 / 4;                // per wave
+    constexpr int NCH = R8 / NW;               // per wave
     const int fr = lane & 15, fq = lane >> 4;
     const unsigned char* src[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int r = (c * 4 + wave) * 8 + (lane >> 3);                 // row of the (A rows, then B rows) tile image
+        const int r = (c * NW + wave) * 8 + (lane >> 3);                // row of the (A rows, then B rows) tile image
         const int lc = (lane & 7) ^ ((r >> 1) & 7);                     // logical chunk this lane fetches
         src[c] = (r < BM ? Ag + (size_t)r * lda_b : Bg + (size_t)(r - BM) * ldb_b) + lc * 16;
     }
@@ -521,7 +536,7 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
     {                                                                                                  \
         _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                                \
             __builtin_amdgcn_global_load_lds((gp_t)(src[c] + (size_t)(kt) * kTileBytesK),              \
-                (lp_t)(smem + (buf) * TileSmem<BM, BN, RING>::kStage + (c * 4 + wave_u) * 1024), 16, 0, 0);  \
+                (lp_t)(smem + (buf) * TileSmem<BM, BN, RING>::kStage + (c * NW + wave_u) * 1024), 16, 0, 0); \
     }
 #define AVAE_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #ifdef AVAE_ABL_NO_DMA      /* diagnostic: loop without the operand refills (results are garbage) */
@@ -531,7 +546,11 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
 #endif
     // The refill DMA of the stage freed by the previous tile is issued between the first slab's
     // fragment reads and its MFMAs, so the issue cost (~60-100 cycles per 1-KiB piece) overlaps
-    // matrix-pipe work instead of preceding it.
+    // matrix-pipe work instead of preceding it.  With 8 waves (two per SIMD: waves i and i+4) one barrier
+    // per tile keeps all waves in step, so both waves of a SIMD would hit their DMA burst -- where the wave
+    // stalls on the CU's vector-memory path and the matrix pipe idles -- at the same time; waves 4-7 therefore
+    // issue their refill AFTER their MFMAs: one wave of each SIMD multiplies while the other issues.
+    const bool dma_late = NW == 8 && wave_u >= 4;
 #define AVAE_COMPUTE(buf, do_dma, dma_kt, dma_buf)                                                     \
     {                                                                                                  \
         const unsigned char* Sb = smem + (buf) * TileSmem<BM, BN, RING>::kStage;                       \
@@ -540,38 +559,64 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
             a0[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + sw0);           \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
             b0[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + sw0);           \
-        if (do_dma) AVAE_ABL_DMA(dma_kt, dma_buf)                                                      \
+        AVAE_LGKM0(); AVAE_LT(2)                                                                       \
+        if ((do_dma) && !dma_late) AVAE_ABL_DMA(dma_kt, dma_buf)                                       \
+        AVAE_LT(3)                                                                                     \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
             a1[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + (sw0 ^ 64));    \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
             b1[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + (sw0 ^ 64));    \
+        AVAE_LGKM0(); AVAE_LT(4)                                                                       \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
             _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a0[i], b0[j], acc[i][j]);           \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
             _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a1[i], b1[j], acc[i][j]);           \
+        if ((do_dma) && dma_late) AVAE_ABL_DMA(dma_kt, dma_buf)                                        \
+        AVAE_MFMA_DRAIN()                                                                              \
+        AVAE_LT(5)                                                                                     \
     }
 
+#if defined(AVAE_STAMPS) && defined(AVAE_LOOPSTAMPS)
+#define AVAE_MFMA_DRAIN() { float d_; asm volatile("v_mov_b32 %0, %1" : "=v"(d_) : "v"(acc[MI - 1][NI - 1][3])); asm volatile("" :: "v"(d_)); }
+#else
+#define AVAE_MFMA_DRAIN()
+#endif
     AVAE_STAMP(1)
     {
         const int npro = nk < RING - 1 ? nk : RING - 1;
         for (int p = 0; p < npro; ++p) AVAE_DMA(p, p)
     }
+    int buf = 0;                               // stage of tile kt; the refill goes to the stage freed by tile kt-1
     for (int kt = 0; kt < nk; ++kt) {
+        AVAE_LT0()
+        const int rem = nk - 1 - kt;           // tiles issued behind kt: min(rem, RING - 2); vmcnt needs an immediate
         if constexpr (RING == 2) {
             AVAE_WAIT(0);
+        } else if constexpr (RING == 3) {
+            if (rem >= 1) AVAE_WAIT(NCH);
+            else AVAE_WAIT(0);
         } else {
-            static_assert(RING == 4, "wait ladder written for RING 2 and 4");
-            const int rem = nk - 1 - kt;       // tiles issued behind kt: min(rem, RING - 2)
+            static_assert(RING == 4, "wait ladder written for RING 2, 3 and 4");
             if (rem >= 2) AVAE_WAIT(2 * NCH);
             else if (rem == 1) AVAE_WAIT(NCH);
             else AVAE_WAIT(0);
         }
+        AVAE_LT(0)
         asm volatile("s_barrier" ::: "memory");
+        AVAE_LT(1)
         if (kt == 0) { AVAE_STAMP(2) }
-        AVAE_COMPUTE(kt & (RING - 1), kt + RING - 1 < nk, kt + RING - 1, (kt + RING - 1) & (RING - 1))
+        const int fill = buf == 0 ? RING - 1 : buf - 1;
+        AVAE_COMPUTE(buf, kt + RING - 1 < nk, kt + RING - 1, fill)
+        buf = buf + 1 == RING ? 0 : buf + 1;
     }
     lds_barrier();
     AVAE_STAMP(3)
+#if defined(AVAE_STAMPS) && defined(AVAE_LOOPSTAMPS)
+    for (int i_ = 0; i_ < 6; ++i_) sv[1 + i_] = la[i_];
+    sv[7] = (unsigned long long)nk;
+    AVAE_STAMP_FLUSH()
+    return;                                    // diagnostic build: no epilogue, results are garbage
+#endif
 #undef AVAE_DMA
 #undef AVAE_WAIT
 #undef AVAE_COMPUTE
@@ -596,15 +641,16 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
     switch (w.kind) {
     case K_FWD_HIDDEN: {
         CT* Y = reinterpret_cast<CT*>(w.out0);
-        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, false, true, BM, BN>(Cs, Y, w.ld0, (const CT*)nullptr, 4, M, N, m0, n0,
+        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, false, true, BM, BN, NT>(Cs, Y, w.ld0, (const CT*)nullptr, 4, M, N, m0, n0,
             [](float c, float, bool) { return act_fwd_t<ACT>(c); })))
         AVAE_STAMP(6)
         if (w.out1) {
             lds_barrier();
-            transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
+            transposed_store<CT, BM, BN, NT>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
         }
     } break;
     case K_FWD_HEAD: {
+      if constexpr (NW == 4) {     // 8-wave tiles carry the plain kinds only (host: finish_launch)
         // columns [0,nz) = mu, [nz,2nz) = log sigma^2 (vae_assoc.py:217-221); z = mu + sqrt(exp(lv))*eps (:102-103)
         const int nz = w.nz;
         float* Zs = Cs + BM * LDC;                         // second fp32 tile: z
@@ -633,8 +679,10 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
                                                     M, nz, m0, 0, [](float c, float, bool) { return c; });
             if (w.out2) transposed_store<CT, BM, BN>(Zs, reinterpret_cast<CT*>(w.out2), w.ld2, M, nz, m0, 0);
         }
+      }
     } break;
     case K_FWD_OUT_LOSS: {
+      if constexpr (NW == 4) {     // 8-wave tiles carry the plain kinds only (host: finish_launch)
         // Bernoulli: -sum x log(1e-3+p) + (1-x) log(1e-3+1-p), p = sigmoid(a)  (:321-324), mean over batch (:340)
         // Gaussian : sum (x-a)^2 / 2 over the WHOLE batch, not averaged          (:327-328,:340)
         CT* dA = reinterpret_cast<CT*>(w.out0);
@@ -665,8 +713,10 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
             lds_barrier();
             transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
         }
+      }
     } break;
     case K_FWD_OUT_STORE: {
+      if constexpr (NW == 4) {     // 8-wave tiles carry the plain kinds only (host: finish_launch)
         float* O = reinterpret_cast<float*>(w.out0);
         if (w.binary)
             tile_pass<float, float, false, false, BM, BN>(Cs, O, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
@@ -674,18 +724,20 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
         else
             tile_pass<float, float, false, false, BM, BN>(Cs, O, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
                 [](float a, float, bool) { return a; });
+      }
     } break;
     case K_DGRAD_HIDDEN: {
         CT* dX = reinterpret_cast<CT*>(w.out0);
         const CT* Yp = reinterpret_cast<const CT*>(w.aux0);
-        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, true, true, BM, BN>(Cs, dX, w.ld0, Yp, w.ldx, M, N, m0, n0,
+        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, true, true, BM, BN, NT>(Cs, dX, w.ld0, Yp, w.ldx, M, N, m0, n0,
             [](float c, float y, bool) { return c * act_bwd_t<ACT>(y); })))
         if (w.out1) {
             lds_barrier();
-            transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
+            transposed_store<CT, BM, BN, NT>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
         }
     } break;
     case K_DGRAD_LATENT: {
+      if constexpr (NW == 4) {     // 8-wave tiles carry the plain kinds only (host: finish_launch)
         // dz -> (dmu, dlv): dmu = dz + g0mu; dlv = dz * F + g0lv with F = 1/2 exp(lv/2) eps   (reparam :102-103);
         // g0 = [g0mu | g0lv | F] per row comes from the K_LATENT item of the forward pass
         const int nz = w.nz;
@@ -717,15 +769,18 @@ __global__ void __launch_bounds__(kThreads, (RING == 2 ? 2 : 1)) k_grouped(const
         tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out0), w.ld0, (const CT*)nullptr, 8,
                                                 M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
         if (w.out1) transposed_store<CT, BM, BN>(Zs, reinterpret_cast<CT*>(w.out1), w.ld1, M, 2 * nz, m0, 0);
+      }
     } break;
     case K_DGRAD_F32:
     case K_WGRAD: {
         float* G = reinterpret_cast<float*>(w.out0);
-        tile_pass<float, float, false, false, BM, BN>(Cs, G, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
+        tile_pass<float, float, false, false, BM, BN, NT>(Cs, G, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
             [](float c, float, bool) { return c; });
     } break;
     case K_WGRAD_ADAM: {
+      if constexpr (NW == 4) {     // 8-wave tiles carry the plain kinds only (host: finish_launch)
         wgrad_adam_pass<CT, BM, BN>(Cs, w, st->lr_t, m0, n0);
+      }
     } break;
     default: break;
     }
@@ -756,17 +811,19 @@ template <typename K> static void set_max_lds(K kernel) {
 void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
                     DevState* st, hipStream_t s, unsigned long long* stamps, int launch_id) {
     static const bool once = [] {
-        set_max_lds(k_grouped<__bf16, 64, 64, 4>); set_max_lds(k_grouped<__bf16, 128, 128, 2>);
-        set_max_lds(k_grouped<float, 64, 64, 4>); set_max_lds(k_grouped<float, 128, 128, 2>);
+        set_max_lds(k_grouped<__bf16, 64, 64, 4>); set_max_lds(k_grouped<__bf16, 128, 128, 2>); set_max_lds(k_grouped<__bf16, 256, 128, 3, 8>);
+        set_max_lds(k_grouped<float, 64, 64, 4>); set_max_lds(k_grouped<float, 128, 128, 2>); set_max_lds(k_grouped<float, 256, 128, 3, 8>);
         return true;
     }();
     (void)once;
-    dim3 grid(grid_x, grid_y), block(kThreads);
+    dim3 grid(grid_x, grid_y), block(tile_cfg == 2 ? 512 : kThreads);
     if (compute_dtype == AVAE_BF16) {
         if (tile_cfg == 0) AVAE_LAUNCH((k_grouped<__bf16, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+        else if (tile_cfg == 2) AVAE_LAUNCH((k_grouped<__bf16, 256, 128, 3, 8>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
         else AVAE_LAUNCH((k_grouped<__bf16, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
     } else {
         if (tile_cfg == 0) AVAE_LAUNCH((k_grouped<float, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+        else if (tile_cfg == 2) AVAE_LAUNCH((k_grouped<float, 256, 128, 3, 8>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
         else AVAE_LAUNCH((k_grouped<float, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
     }
 }
