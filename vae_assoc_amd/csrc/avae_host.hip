@@ -720,11 +720,26 @@ void build_training_plan(avae_handle* h) {
         }
         std::vector<Launch>& dst = fused ? h->wg_adam : h->wg_plain;
         dst.clear();
-        for (size_t i0 = 0; i0 < wg.size(); i0 += kMaxItemsPerLaunch) {
-            const size_t i1 = std::min(wg.size(), i0 + kMaxItemsPerLaunch);
-            group(std::string(fused ? "wgrad_adam" : "wgrad") + (wg.size() > (size_t)kMaxItemsPerLaunch ? std::to_string(i0 / kMaxItemsPerLaunch + 1) : ""),
-                  dst, [&] { for (size_t i = i0; i < i1; ++i) h->items.push_back(wg[i]); });
+        // big problems: the narrow products (heads, first decoder layer) get launches of their own, or their presence
+        // would hold the wide ones on 64x64 tiles (finish_launch picks one tile shape per launch)
+        auto is_narrow = [](const WorkItem& w) { return w.N <= 64 || w.M <= 64; };
+        long wide128 = 0;
+        for (const WorkItem& w : wg) if (!is_narrow(w)) wide128 += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
+        std::vector<std::vector<WorkItem>> chunks;
+        auto chunk_up = [&](const std::vector<WorkItem>& v) {
+            for (size_t i0 = 0; i0 < v.size(); i0 += kMaxItemsPerLaunch)
+                chunks.emplace_back(v.begin() + i0, v.begin() + std::min(v.size(), i0 + kMaxItemsPerLaunch));
+        };
+        if (wide128 >= 192) {
+            std::vector<WorkItem> wide, narrow;
+            for (const WorkItem& w : wg) (is_narrow(w) ? narrow : wide).push_back(w);
+            chunk_up(wide); chunk_up(narrow);
+        } else {
+            chunk_up(wg);
         }
+        for (size_t c = 0; c < chunks.size(); ++c)
+            group(std::string(fused ? "wgrad_adam" : "wgrad") + (chunks.size() > 1 ? std::to_string(c + 1) : ""), dst,
+                  [&] { for (const WorkItem& w : chunks[c]) h->items.push_back(w); });
     }
     // Single replica: fuse Adam into the weight-gradient epilogues only while those launches fit the chip in one
     // resident round.  A fused tile's epilogue streams 448 KB (theta, m, v in and out, both shadows); when every
