@@ -87,7 +87,7 @@ def launch_work(archs, B, es, fused_adam=True):
         add("fwd_head", (B * i + (i + 1) * o) * es + B * o * 4 + B * nz * (4 + es), 2 * B * (i + 1) * o)
         for k, (i, o) in enumerate(dec):
             add("fwd_dec%d" % (k + 1), (B * i + (i + 1) * o + B * o) * es, 2 * B * (i + 1) * o)
-        add("fwd_dec1", B * (2 + 3) * nz * 4, 0)                                 # latent item: mulv in, static grads out
+        add("fwd_out_loss", B * (2 + 3) * nz * 4, 0)                             # latent item (rides in this launch): mulv in, static grads out
         i, o = outl
         add("fwd_out_loss", (B * i + (i + 1) * o + B * o) * es + B * o * 4, 2 * B * (i + 1) * o)
 

@@ -645,7 +645,6 @@ void build_training_plan(avae_handle* h) {
     for (int k = 0; k < std::max(Lmax, 1); ++k)
         group("fwd_dec" + std::to_string(k + 1), h->fwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k]));
-            if (k == 0) h->items.push_back(bd.latent());     // needs every modality's (mu, lv): ready after fwd_head
         });
     if (any_conv) {   // deconv decoder: (im2col of the dilated input, GEMM + bias + sigmoid) x 4, then flatten for the dense output
         for (int i = 0; i < 4; ++i) {
@@ -656,7 +655,12 @@ void build_training_plan(avae_handle* h) {
         gather_launch("conv_out_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cdec[4]; },
                       [&](Mod& md) { return h->at<void>(md.cdec[3].Y.rm); });
     }
-    group("fwd_out_loss", h->fwd, [&] { for (int m = 0; m < h->M; ++m) h->items.push_back(bd.fwd_out(h->mods[m], m, true)); });
+    group("fwd_out_loss", h->fwd, [&] {
+        for (int m = 0; m < h->M; ++m) h->items.push_back(bd.fwd_out(h->mods[m], m, true));
+        // KL + association terms and their (mu, lv) gradients: need every modality's (mu, lv) (ready after fwd_head) and are
+        // needed by bwd_dec1_latent; they ride here so that the decoder's hidden launches stay plain GEMM launches
+        h->items.push_back(bd.latent());
+    });
     // ---- backward: the dgrad chain (one launch per layer, all modalities), then EVERY weight
     // gradient in one final wave of launches: they depend only on stored activations / activation
     // gradients, and being last lets the single-replica path fuse Adam + shadow refresh into their
@@ -682,13 +686,15 @@ void build_training_plan(avae_handle* h) {
         group("bwd_dec" + std::to_string(k + 1), h->bwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.dgrad_hidden(md.dD[k], md.dec[k], md.D[k - 1], md.dD[k - 1]));
         });
-    group("bwd_dec1_latent", h->bwd, [&] { for (Mod& md : h->mods) if (!md.conv) h->items.push_back(bd.dgrad_latent(md)); });
+    group("bwd_dec1_latent", h->bwd, [&] {
+        for (Mod& md : h->mods) if (!md.conv) h->items.push_back(bd.dgrad_latent(md));
+        h->items.push_back(bd.cost(true));                       // every cost partial is final since fwd_out_loss: cost, step counter, lr_t
+    });
     group("bwd_head", h->bwd, [&] {
         for (Mod& md : h->mods) {
             if (md.conv) h->items.push_back(bd.conv_dgrad(md.cenc[3], md.dH));
             else h->items.push_back(bd.dgrad_hidden(md.dH, md.head, md.E.back(), md.dE.back()));
         }
-        h->items.push_back(bd.cost(true));                       // every cost partial is final by now: cost, step counter, lr_t
     });
     if (any_conv) {
         for (int i = 3; i >= 1; --i) {
