@@ -21,7 +21,7 @@ def main():
     trace, order_file = sys.argv[1], sys.argv[2]
     names = json.load(open(order_file))["order"]
     rows = [r for r in csv.DictReader(open(trace)) if "k_prep" in r["Kernel_Name"] or "k_grouped" in r["Kernel_Name"]
-            or "k_gather" in r["Kernel_Name"] or "k_col2im" in r["Kernel_Name"]]
+            or "k_gather" in r["Kernel_Name"] or "k_col2im" in r["Kernel_Name"] or "k_adam" in r["Kernel_Name"]]
     steps, cur = [], None
     for r in rows:
         if "k_prep" in r["Kernel_Name"]:
@@ -38,7 +38,8 @@ def main():
     for j, name in enumerate(["prep"] + names):
         d = [(int(s[j]["End_Timestamp"]) - int(s[j]["Start_Timestamp"])) / 1e3 for s in steps]
         out[name] = {"calls": len(d), "avg_us": round(sum(d) / len(d), 2), "min_us": round(min(d), 2),
-                     "workgroups": int(steps[0][j]["Grid_Size_X"]) // int(steps[0][j]["Workgroup_Size_X"])}
+                     "workgroups": (int(steps[0][j]["Grid_Size_X"]) // int(steps[0][j]["Workgroup_Size_X"]))
+                                   * (int(steps[0][j]["Grid_Size_Y"]) // int(steps[0][j]["Workgroup_Size_Y"]))}
     span = [(int(s[-1]["End_Timestamp"]) - int(s[0]["Start_Timestamp"])) / 1e3 for s in steps]
     print(json.dumps({"source": "rocprofv3 --kernel-trace, %d graph-replayed steps" % len(steps),
                       "launches": out, "sum_avg_us": round(sum(v["avg_us"] for v in out.values()), 2),
