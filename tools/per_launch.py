@@ -22,6 +22,7 @@ def main():
     names = json.load(open(order_file))["order"]
     rows = [r for r in csv.DictReader(open(trace)) if "k_prep" in r["Kernel_Name"] or "k_grouped" in r["Kernel_Name"]
             or "k_gather" in r["Kernel_Name"] or "k_col2im" in r["Kernel_Name"] or "k_adam" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))            # the CSV is not in execution order
     steps, cur = [], None
     for r in rows:
         if "k_prep" in r["Kernel_Name"]:
