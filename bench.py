@@ -66,7 +66,7 @@ def dense_layers(na):
     return enc, head, dec, (prev, n_in)
 
 
-def launch_work(archs, B, es, fused_adam=True):
+def launch_work(archs, B, es):
     """Algorithmic HBM bytes and FLOPs of every launch of one step (SURVEY.md 8d accounting:
     operands read once, results written once, compute-dtype activations, fp32 Adam state).
     Launch names mirror avae_host.hip::build_training_plan."""
@@ -117,9 +117,7 @@ def launch_work(archs, B, es, fused_adam=True):
     for c0 in range(0, len(wg), chunk):
         suffix = str(c0 // chunk + 1) if len(wg) > chunk else ""
         for by, fl, p in wg[c0:c0 + chunk]:
-            # fused: theta/m/v read+write (6 x 4 B) + one compute-dtype shadow; the gradient never has to reach HBM
-            add("wgrad_adam" + suffix, by + p * (6 * 4 + es), fl)
-            add("wgrad" + suffix, by + p * 4, fl)                                # plain: fp32 gradient out
+            add("wgrad" + suffix, by + p * 4, fl)                                # fp32 gradient out
     add("adam", 7 * P * 4 + P * es, 0)
     return out, P
 

@@ -26,5 +26,5 @@ for tag, defs in (("full", []), ("no_mfma", ["-DAVAE_ABL_NO_MFMA"]), ("no_dma", 
         continue
     j = json.loads(line[-1])
     k = j["kernels_us"]
-    print("%-8s ms/step %.3f  fwd_enc2 %.1f  fwd_dec2 %.1f  bwd_dec2 %.1f  wgrad_adam1 %.1f" % (
-        tag, j["ms_per_step"], k.get("fwd_enc2", 0), k.get("fwd_dec2", 0), k.get("bwd_dec2", 0), k.get("wgrad_adam1", k.get("wgrad_adam", 0))))
+    print("%-8s ms/step %.3f  fwd_enc2 %.1f  fwd_dec2 %.1f  bwd_dec2 %.1f  wgrad1 %.1f" % (
+        tag, j["ms_per_step"], k.get("fwd_enc2", 0), k.get("fwd_dec2", 0), k.get("bwd_dec2", 0), k.get("wgrad1", k.get("wgrad", 0))))

@@ -5,7 +5,7 @@
 
 k_grouped runs every GEMM launch of the step, so rocprofv3's per-kernel-name statistics lump them
 together.  A graph replay issues the launches in a fixed order (k_prep, then the launches in the order
-bench.py's `kernels_us` names them in the plan: fwd_*, bwd_*, wgrad_adam*), so the n-th dispatch after a
+bench.py's `kernels_us` names them in the plan: fwd_*, bwd_*, wgrad*), so the n-th dispatch after a
 k_prep is the n-th launch of the plan.  Steps whose dispatch count differs (warm-up, the eager timing
 pass) are skipped.
 """

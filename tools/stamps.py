@@ -45,14 +45,14 @@ def main():
     assert rc == 0, model._L.avae_last_error(model._h)
     st = buf.reshape(nl, nb, nw).astype(np.int64)
     names = ['fwd_enc1', 'fwd_enc2', 'fwd_head', 'fwd_dec1', 'fwd_dec2', 'fwd_out_loss', 'bwd_out', 'bwd_dec2',
-             'bwd_dec1_latent', 'bwd_head', 'bwd_enc2', 'wgrad_adam']
+             'bwd_dec1_latent', 'bwd_head', 'bwd_enc2', 'wgrad']
     print("%-16s %6s %8s | %7s %7s %7s %7s | %8s %7s  (us; realtime ticks are 10 ns)" % (
         "launch", "blocks", "span", "lookup", "tile0", "kloop", "epilog", "startspr", "clkMHz"))
     prev_end = None
     if cfg == "c4":
         names = ['fwd_enc1', 'fwd_enc2', 'fwd_enc3', 'fwd_enc4', 'fwd_head', 'fwd_dec1', 'fwd_dec2', 'fwd_dec3', 'fwd_dec4',
                  'fwd_out_loss', 'bwd_out', 'bwd_dec4', 'bwd_dec3', 'bwd_dec2', 'bwd_dec1_latent', 'bwd_head',
-                 'bwd_enc4', 'bwd_enc3', 'bwd_enc2', 'wgrad_adam1', 'wgrad_adam2']
+                 'bwd_enc4', 'bwd_enc3', 'bwd_enc2', 'wgrad1', 'wgrad2']
     for l in range(min(nl, len(names))):
         s = st[l]
         live = s[:, 0] > 0

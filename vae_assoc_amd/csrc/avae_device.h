@@ -25,7 +25,6 @@ enum Kind : int {
     K_DGRAD_HIDDEN = 4,  // dA_prev = (dA . W^T) * act'(Y_prev)        -> dA_prev, dA_prev^T
     K_DGRAD_LATENT = 5,  // dz = dA . V1^T; dmu, dlv via reparam + static latent grads -> dH, dH^T
     K_WGRAD = 6,         // dW_aug = X_aug^T . dA (bias grad = last row) -> fp32 gradient
-    K_WGRAD_ADAM = 9,    // the same product with the TF-1 Adam update + shadow refresh fused into its epilogue
     K_DGRAD_F32 = 10,    // dP = dA . W^T stored as fp32 (conv branch: patch gradients, summed by k_col2im)
     K_LATENT = 7,        // KL(q||N(0,I)) + association penalty: cost partials + static (mu,lv) grads (:335-366)
     K_COST = 8,          // fixed-order sum of the cost partials -> grad[cost slot]; bumps the step counter
@@ -74,8 +73,7 @@ constexpr int kMaxItemsPerLaunch = 12;
 struct LaunchArgs {
     int n_items;
     int grid_x;
-    int stagger_sleeps;                     // > 0: workgroups 256..511 (the second resident slot of every CU) start that many
-    int pad;                                //      s_sleep(127) periods late, see k_grouped
+    int pad[2];
     WorkItem items[kMaxItemsPerLaunch];
 };
 

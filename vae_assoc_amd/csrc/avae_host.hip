@@ -117,8 +117,7 @@ struct avae_handle {
 
     std::vector<WorkItem> items;            // training + eval tables (host mirror)
     std::vector<Launch> fwd, bwd;           // training launches: forward, dgrad chain
-    std::vector<Launch> wg_plain, wg_adam;  // all weight gradients: plain (-> all-reduce -> k_adam) or with Adam fused
-    bool fuse_adam = true;                  // single replica: wg_adam, or wg_plain + k_adam (see build_training_plan)
+    std::vector<Launch> wgrad;              // all weight gradients (-> [all-reduce ->] k_adam)
     Launch cost_only;                       // eval: K_COST alone, no step bump
     std::vector<AdamItem> adam_items;
     int adam_blocks = 0;
@@ -126,7 +125,7 @@ struct avae_handle {
     struct Inf { std::vector<WorkItem> items; std::vector<Launch> launches; int rows = -1; size_t dev_off = 0; };
     std::vector<Inf> inf_enc, inf_dec;
 
-    hipGraphExec_t g_full = nullptr, g_bwd = nullptr, g_adam = nullptr, g_eval = nullptr;
+    hipGraphExec_t g_full = nullptr, g_bwd = nullptr, g_eval = nullptr;
     hipGraphExec_t g_multi = nullptr;       // kMultiSteps whole steps (avae_train_steps)
     hipGraph_t g_full_graph = nullptr, g_multi_graph = nullptr;   // templates, kept: their staging-kernel nodes are re-parameterised per replay
     std::vector<hipGraphNode_t> g_full_prep, g_multi_prep;
@@ -472,17 +471,9 @@ struct Builder {
         c.tiles_r = (R + 63) / 64; c.tiles_c = (C + 63) / 64;
         return c;
     }
-    WorkItem wgrad(const Act& x, const Dense& d, const Act& dA, bool adam = false) {
-        WorkItem w = gemm_item(adam ? K_WGRAD_ADAM : K_WGRAD, d.in + 1, d.out, K_of(x.rows), p<void>(x.tr), x.ldT, p<void>(dA.tr), dA.ldT);
+    WorkItem wgrad(const Act& x, const Dense& d, const Act& dA) {
+        WorkItem w = gemm_item(K_WGRAD, d.in + 1, d.out, K_of(x.rows), p<void>(x.tr), x.ldT, p<void>(dA.tr), dA.ldT);
         w.out0 = h->grad() + d.master; w.ld0 = d.ld;
-        if (adam) {
-            w.out1 = p<void>(d.W); w.ld1 = d.ld;
-            w.out2 = p<void>(d.Wt); w.ld2 = d.ldt;
-            w.aux0 = p<float>(h->off_theta) + d.master;
-            w.aux1 = p<float>(h->off_m) + d.master;
-            w.aux2 = p<float>(h->off_v) + d.master;
-            w.scale = h->cfg.beta1; w.lambda = h->cfg.beta2; w.inv_bg = h->cfg.adam_eps;
-        }
         return w;
     }
     WorkItem latent() {
@@ -514,7 +505,7 @@ struct Builder {
 
 constexpr int kMultiSteps = 8;          // whole steps per replay of the multi-step graph
 
-inline bool is_gemm(int kind) { return kind <= K_WGRAD || kind == K_WGRAD_ADAM || kind == K_DGRAD_F32; }
+inline bool is_gemm(int kind) { return kind <= K_WGRAD || kind == K_DGRAD_F32; }
 
 // Fixes the tile configuration of one launch and lays its items' tiles out back to back.
 Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, int count, const std::string& name, int* next_slot) {
@@ -571,15 +562,6 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
     if (count > kMaxItemsPerLaunch) throw Err("internal error: too many items in one launch");
     std::memset(&L.args, 0, sizeof(L.args));
     L.args.n_items = count;
-    {   // see k_grouped: stagger the second resident slot when a 128x128-tile launch of fused weight gradients runs several rounds
-        bool all_wga = L.cfg == 1 && L.blocks > 2 * 256;
-        int nk_max = 0;
-        for (int i = first; i < first + count; ++i) {
-            all_wga = all_wga && items[i].kind == K_WGRAD_ADAM;
-            nk_max = std::max(nk_max, items[i].K / h->KU);
-        }
-        if (all_wga) L.args.stagger_sleeps = std::max(1, nk_max / 6);     // ~3.4 us per sleep period: about half of a tile's K loop
-    }
     L.args.grid_x = L.grid_x;
     for (int i = 0; i < count; ++i) L.args.items[i] = items[first + i];
     if (*next_slot > h->n_partial) throw Err("internal error: cost partial slots overflow");
@@ -587,7 +569,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
 }
 
 void build_training_plan(avae_handle* h) {
-    h->items.clear(); h->fwd.clear(); h->bwd.clear(); h->wg_plain.clear(); h->wg_adam.clear();
+    h->items.clear(); h->fwd.clear(); h->bwd.clear(); h->wgrad.clear();
     Builder bd(h, h->items, h->B, true);
     int slot = 0;
     int Lmax = 0;
@@ -707,25 +689,28 @@ void build_training_plan(avae_handle* h) {
         group("bwd_enc" + std::to_string(k + 1), h->bwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.dgrad_hidden(md.dE[k], md.enc[k], md.E[k - 1], md.dE[k - 1]));
         });
-    for (int fused = 0; fused < 2; ++fused) {
+    // ---- every weight gradient in the last launch(es) of the step: they depend only on stored activations /
+    // activation gradients, and nothing reads the weights after them, so k_adam follows directly (after the all-reduce
+    // under data parallelism).  Fusing Adam into these epilogues was measured and dropped: equal on the small nets
+    // (C2 91.5 vs 91.2 us/step), slower on the big ones (C4 958 vs 922: a fused tile streams 448 KB and stalls the
+    // MFMA loops it alternates with).
+    {
         std::vector<WorkItem> wg;
         for (Mod& md : h->mods) {
             if (md.conv) {
-                wg.push_back(bd.wgrad(md.cdec[4].P, md.cdec[4].d, md.dO, fused));
-                for (int i = 3; i >= 0; --i) wg.push_back(bd.wgrad(md.cdec[i].P, md.cdec[i].d, md.cdec[i].dY, fused));
-                wg.push_back(bd.wgrad(md.cenc[3].P, md.cenc[3].d, md.dH, fused));
-                for (int i = 2; i >= 0; --i) wg.push_back(bd.wgrad(md.cenc[i].P, md.cenc[i].d, md.cenc[i].dY, fused));
+                wg.push_back(bd.wgrad(md.cdec[4].P, md.cdec[4].d, md.dO));
+                for (int i = 3; i >= 0; --i) wg.push_back(bd.wgrad(md.cdec[i].P, md.cdec[i].d, md.cdec[i].dY));
+                wg.push_back(bd.wgrad(md.cenc[3].P, md.cenc[3].d, md.dH));
+                for (int i = 2; i >= 0; --i) wg.push_back(bd.wgrad(md.cenc[i].P, md.cenc[i].d, md.cenc[i].dY));
                 continue;
             }
-            wg.push_back(bd.wgrad(md.D.back(), md.outl, md.dO, fused));
-            for (int k = md.L - 1; k >= 1; --k) wg.push_back(bd.wgrad(md.D[k - 1], md.dec[k], md.dD[k], fused));
-            wg.push_back(bd.wgrad(md.Z, md.dec[0], md.dD[0], fused));
-            wg.push_back(bd.wgrad(md.E.back(), md.head, md.dH, fused));
-            for (int k = md.L - 1; k >= 1; --k) wg.push_back(bd.wgrad(md.E[k - 1], md.enc[k], md.dE[k], fused));
-            wg.push_back(bd.wgrad(md.X0, md.enc[0], md.dE[0], fused));
+            wg.push_back(bd.wgrad(md.D.back(), md.outl, md.dO));
+            for (int k = md.L - 1; k >= 1; --k) wg.push_back(bd.wgrad(md.D[k - 1], md.dec[k], md.dD[k]));
+            wg.push_back(bd.wgrad(md.Z, md.dec[0], md.dD[0]));
+            wg.push_back(bd.wgrad(md.E.back(), md.head, md.dH));
+            for (int k = md.L - 1; k >= 1; --k) wg.push_back(bd.wgrad(md.E[k - 1], md.enc[k], md.dE[k]));
+            wg.push_back(bd.wgrad(md.X0, md.enc[0], md.dE[0]));
         }
-        std::vector<Launch>& dst = fused ? h->wg_adam : h->wg_plain;
-        dst.clear();
         // big problems: the narrow products (heads, first decoder layer) get launches of their own, or their presence
         // would hold the wide ones on 64x64 tiles (finish_launch picks one tile shape per launch)
         auto is_narrow = [](const WorkItem& w) { return w.N <= 64 || w.M <= 64; };
@@ -744,19 +729,8 @@ void build_training_plan(avae_handle* h) {
             chunk_up(wg);
         }
         for (size_t c = 0; c < chunks.size(); ++c)
-            group(std::string(fused ? "wgrad_adam" : "wgrad") + (chunks.size() > 1 ? std::to_string(c + 1) : ""), dst,
+            group("wgrad" + (chunks.size() > 1 ? std::to_string(c + 1) : std::string()), h->wgrad,
                   [&] { for (const WorkItem& w : chunks[c]) h->items.push_back(w); });
-    }
-    // Single replica: fuse Adam into the weight-gradient epilogues only while those launches fit the chip in one
-    // resident round.  A fused tile's epilogue streams 448 KB (theta, m, v in and out, both shadows); when every
-    // CU works through a queue of such tiles (C4: 1250 tiles of 64 K-steps) they stall the MFMA loops they
-    // alternate with, and plain weight gradients + the streaming k_adam are faster (C4: 922 vs 958 us/step);
-    // for the small nets the fused form saves a kernel (C2: 96.4 vs 101.8 us/step).
-    {
-        long blocks = 0;
-        for (const Launch& L : h->wg_adam) blocks += L.blocks;
-        h->fuse_adam = blocks <= 2 * 256 * 4;
-        for (const Launch& L : h->wg_adam) if (L.cfg == 1 && L.blocks > 2 * 256) h->fuse_adam = false;
     }
     // ---- eval: forward launches + a lone cost reduction that does not bump the step
     {
@@ -1053,14 +1027,13 @@ void init_device(avae_handle* h) {
     if (h->cfg.use_graph) {
         const bool tsave = h->timing;
         h->timing = false;
-        h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, h->bwd, cs); run_launches(h, h->wg_plain, cs); });
-        h->g_adam = capture(h, [&](hipStream_t cs) { run_adam(h, 0, cs); });
+        h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, h->bwd, cs); run_launches(h, h->wgrad, cs); });
         std::vector<const float*> x0(h->M, h->at<float>(h->mods[0].X32));    // placeholders, patched per step
         auto one_step = [&](hipStream_t cs) {
             run_prep_batch(h, x0.data(), nullptr, nullptr, h->B, 0x7261696eull, cs);
             run_launches(h, h->fwd, cs, 0); run_launches(h, h->bwd, cs, (int)h->fwd.size());
-            if (h->fuse_adam) run_launches(h, h->wg_adam, cs, (int)(h->fwd.size() + h->bwd.size()));
-            else { run_launches(h, h->wg_plain, cs, (int)(h->fwd.size() + h->bwd.size())); run_adam(h, 0, cs); }
+            run_launches(h, h->wgrad, cs, (int)(h->fwd.size() + h->bwd.size()));
+            run_adam(h, 0, cs);
         };
         h->g_full = capture_with_prep(h, 1, one_step, &h->g_full_graph, &h->g_full_prep);
         // avae_train_steps: kMultiSteps whole steps per replay (a replay boundary costs ~5 us of idle GPU on this stack)
@@ -1072,12 +1045,13 @@ void init_device(avae_handle* h) {
 
 void do_backward(avae_handle* h, hipStream_t s) {
     if (h->g_bwd && !h->timing) HIP_OK(hipGraphLaunch(h->g_bwd, s));
-    else { run_launches(h, h->fwd, s); run_launches(h, h->bwd, s); run_launches(h, h->wg_plain, s); }
+    else { run_launches(h, h->fwd, s); run_launches(h, h->bwd, s); run_launches(h, h->wgrad, s); }
 }
 
 void do_apply(avae_handle* h, hipStream_t s) {
-    if (h->g_adam && !h->timing) HIP_OK(hipGraphLaunch(h->g_adam, s));
-    else run_adam(h, 0, s);
+    // one kernel: launched directly (a graph replay boundary costs ~5 us of idle GPU, a launch ~5 us of host time:
+    // C2 seam path 95.6 vs 101.2 us/step)
+    run_adam(h, 0, s);
 }
 
 void fetch_cost(avae_handle* h, float* cost_host, bool from_state, hipStream_t s) {
@@ -1174,7 +1148,7 @@ void avae_destroy(avae_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
-    for (hipGraphExec_t g : {h->g_full, h->g_multi, h->g_bwd, h->g_adam, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
+    for (hipGraphExec_t g : {h->g_full, h->g_multi, h->g_bwd, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
     for (hipGraph_t g : {h->g_full_graph, h->g_multi_graph}) if (g) (void)hipGraphDestroy(g);
     for (TimingRec& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -1253,8 +1227,8 @@ void train_one(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, c
     }
     run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, s);
     run_launches(h, h->fwd, s); run_launches(h, h->bwd, s);
-    if (h->fuse_adam) run_launches(h, h->wg_adam, s);
-    else { run_launches(h, h->wg_plain, s); run_adam(h, 0, s); }
+    run_launches(h, h->wgrad, s);
+    run_adam(h, 0, s);
     if (h->timing) {      // floor of the measurement: a one-store kernel (partial slot 0 is rewritten every step anyway)
         Timed t(h, s, "_null_kernel");
         launch_fill(h->at<void>(h->off_partial), 4, 0u, 0, 1, 1, s);

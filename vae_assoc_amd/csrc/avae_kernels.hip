@@ -256,77 +256,6 @@ __device__ __forceinline__ void transposed_store(const float* Cs, OT* out, int l
     }
 }
 
-template <typename T> __device__ __forceinline__ void store8(T* p, const float* v, int nvalid);
-template <> __device__ __forceinline__ void store8<float>(float* p, const float* v, int nvalid) {
-    store_row<float>(p, v, nvalid);
-    if (nvalid > 4) store_row<float>(p + 4, v + 4, nvalid - 4);
-}
-template <> __device__ __forceinline__ void store8<__bf16>(__bf16* p, const float* v, int nvalid) { store_vec<__bf16, 8>(p, v, nvalid); }
-
-// K_WGRAD_ADAM epilogue: the fp32 gradient tile is in LDS; apply TF-1 Adam (vae_assoc.py:373-374:
-// m += (g-m)(1-b1); v += (g^2-v)(1-b2); theta -= lr_t m/(sqrt(v)+eps)) to the matching tile of
-// theta/m/v and refresh both compute-dtype shadows, so no separate optimiser kernel and no
-// gradient round trip through HBM is needed on a single replica.  Pointers: out0 = g (still
-// written: avae_get_grads), out1 = W shadow, out2 = W^T shadow, aux0/1/2 = theta/m/v.
-template <typename CT, int BM, int BN>
-__device__ __forceinline__ void wgrad_adam_pass(float* Cs, const WorkItem& w, float lr_t, int m0, int n0) {
-    constexpr int LDC = BN + 4, QC = BN / 8, NQT = BM * QC / kThreads;
-    constexpr int NQ = 2;                      // octets per thread handled together (bounds the register footprint)
-    static_assert(NQT % NQ == 0, "tile / thread mapping");
-    const int tid = threadIdx.x, M = w.M, N = w.N, ld = w.ld0;
-    float* G = reinterpret_cast<float*>(w.out0);
-    float* TH = reinterpret_cast<float*>(const_cast<void*>(w.aux0));
-    float* MM = reinterpret_cast<float*>(const_cast<void*>(w.aux1));
-    float* VV = reinterpret_cast<float*>(const_cast<void*>(w.aux2));
-    CT* W = reinterpret_cast<CT*>(w.out1);
-    const float omb1 = 1.0f - w.scale, omb2 = 1.0f - w.lambda, aeps = w.inv_bg;
-    for (int q0 = 0; q0 < NQT; q0 += NQ) {
-        float g[NQ][8], th[NQ][8], mm[NQ][8], vv[NQ][8];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + cs_idx<LDC>(row, c0 + 4 * h));
-                g[q][4 * h] = t[0]; g[q][4 * h + 1] = t[1]; g[q][4 * h + 2] = t[2]; g[q][4 * h + 3] = t[3];
-            }
-            const size_t off = (size_t)min(m0 + row, M - 1) * ld + min(n0 + c0, ld - 8);     // clamped => never stored
-            load_vec<float, 8>(TH + off, th[q]);
-            load_vec<float, 8>(MM + off, mm[q]);
-            load_vec<float, 8>(VV + off, vv[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                mm[q][e] += (g[q][e] - mm[q][e]) * omb1;
-                vv[q][e] += (g[q][e] * g[q][e] - vv[q][e]) * omb2;
-                th[q][e] -= (mm[q][e] * lr_t) / (sqrtf(vv[q][e]) + aeps);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                *reinterpret_cast<f32x4*>(Cs + cs_idx<LDC>(row, c0 + 4 * h)) = f32x4{th[q][4 * h], th[q][4 * h + 1], th[q][4 * h + 2], th[q][4 * h + 3]};
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + (q0 + q) * kThreads, row = idx / QC, c0 = (idx - row * QC) * 8;
-            const int grow = m0 + row, gcol = n0 + c0;
-            if (grow < M && gcol < N) {
-                const size_t off = (size_t)grow * ld + gcol;
-                const int nv = N - gcol;
-                store8<float>(G + off, g[q], nv);
-                store8<float>(TH + off, th[q], nv);
-                store8<float>(MM + off, mm[q], nv);
-                store8<float>(VV + off, vv[q], nv);
-                store8<CT>(W + off, th[q], nv);
-            }
-        }
-    }
-    lds_barrier();
-    transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out2), w.ld2, M, N, m0, n0);
-}
-
 // ------------------------------------------------------------------ non-GEMM work items
 // KL(q||N(0,I)) (vae_assoc.py:335-337) and the symmetric-KL association penalty (:346-366) with
 // their gradients w.r.t. (mu, lv).  The log-determinant terms of the two directed KLs cancel, so
@@ -462,13 +391,6 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
 #endif
 
     const WorkItem w = args.items[blockIdx.y];                    // one burst of scalar loads from the kernarg segment
-    // Multi-round launches of long weight-gradient tiles (two resident workgroups per CU): the MFMA-bound K loop
-    // is followed by an HBM-bound Adam epilogue, and workgroups that start together hit both phases together.
-    // Starting the second resident slot of every CU about half a tile late keeps the two slots out of phase for
-    // the rest of the launch (a slot runs its queue of tiles back to back), so one streams while the other
-    // multiplies.  Placement is not guaranteed -- only speed depends on it.
-    if (args.stagger_sleeps > 0 && ((blockIdx.y * args.grid_x + blockIdx.x) >> 8) == 1)
-        for (int i = 0; i < args.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     // XCD-aware tile order inside the item: hardware deals workgroups round-robin over the 8 XCDs
     // (private 4 MiB L2 each) in linear order y*grid_x + x, and grid_x is a multiple of 8, so x%8 names the XCD group.
     // Each group gets one contiguous chunk of the item's tile list (tiles that share A row panels /
@@ -776,11 +698,6 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
         float* G = reinterpret_cast<float*>(w.out0);
         tile_pass<float, float, false, false, BM, BN, NT>(Cs, G, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
             [](float c, float, bool) { return c; });
-    } break;
-    case K_WGRAD_ADAM: {
-      if constexpr (NW == 4) {     // 8-wave tiles carry the plain kinds only (host: finish_launch)
-        wgrad_adam_pass<CT, BM, BN>(Cs, w, st->lr_t, m0, n0);
-      }
     } break;
     default: break;
     }
