@@ -131,6 +131,11 @@ struct PrepArgs {
     unsigned long long seed;
     const DevState* st;
     unsigned long long stream_salt;   // distinguishes train / eval / reconstruct draws
+    // batched staging (avae_train_steps): the launch stages n_steps consecutive batches at once.  Batch j reads rows
+    // [j*rows, (j+1)*rows) of every source (and of eps_src), writes staging set j (every destination moved by
+    // j*set_stride bytes) and draws eps for step st->step + j.  blocks_per_step = total_tiles + eps_blocks.
+    int n_steps, blocks_per_step;
+    long long set_stride;
 };
 
 // Conv / transposed-conv layers (reference vae_assoc.py:169-199,249-278, deconv.py:107) run on the

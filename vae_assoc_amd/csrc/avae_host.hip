@@ -31,6 +31,8 @@ struct Err : std::runtime_error { using std::runtime_error::runtime_error; };
                       std::to_string(__LINE__) + ")");                                           \
     } while (0)
 
+constexpr int kMultiSteps = 8;          // whole steps per replay of the multi-step graph (avae_train_steps)
+
 inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ----------------------------------------------------------------------------- memory plan
@@ -108,6 +110,7 @@ struct avae_handle {
     std::vector<Mod> mods;
     size_t P_flat = 0, P_int = 0;            // flat API count, internal padded count (floats)
     size_t off_theta = 0, off_m = 0, off_v = 0, off_g = 0;   // byte offsets; g has P_int + 64 floats
+    size_t stage_lo = 0, stage_bytes = 0;   // input-staging set 0 (X0 / X32 of every modality + eps); sets 1..kMultiSteps-1 follow it
     size_t off_eps = 0, off_partial = 0, off_state = 0, off_items = 0, off_adam = 0, off_inf = 0, off_stamps = 0, off_latent = 0;
     int n_partial = 0;
     size_t ws_bytes = 0;
@@ -128,7 +131,7 @@ struct avae_handle {
     hipGraphExec_t g_full = nullptr, g_bwd = nullptr, g_eval = nullptr;
     hipGraphExec_t g_multi = nullptr;       // kMultiSteps whole steps (avae_train_steps)
     hipGraph_t g_full_graph = nullptr, g_multi_graph = nullptr;   // templates, kept: their staging-kernel nodes are re-parameterised per replay
-    std::vector<hipGraphNode_t> g_full_prep, g_multi_prep;
+    hipGraphNode_t g_full_prep = nullptr, g_multi_prep = nullptr;
 
     bool timing = false;
     bool debug_sync = false;
@@ -204,6 +207,20 @@ void plan_memory(avae_handle* h) {
     Bump b;
     size_t pint = 0, pflat = 0;
     h->mods.clear();
+    // Input staging first, as one contiguous block, followed by kMultiSteps-1 more copies of it: the multi-step graph
+    // stages all its batches with one launch and step j of a replay reads set j (build_training_plan relocates the
+    // pointers); every other path uses set 0.
+    std::vector<Act> stage_x0(h->M);
+    std::vector<size_t> stage_x32(h->M);
+    h->stage_lo = b.off;
+    for (int m = 0; m < h->M; ++m) {
+        const avae_modality& mo = c.mod[m];
+        stage_x0[m] = make_act(b, mo.n_input, mo.hidden_conv == 0, B, KU, es);
+        stage_x32[m] = b.take((size_t)B * rup(mo.n_input, 8) * 4);
+    }
+    h->off_eps = b.take((size_t)B * h->ld_eps * 4);
+    h->stage_bytes = b.off - h->stage_lo;
+    b.take(h->stage_bytes * (kMultiSteps - 1));
     for (int m = 0; m < h->M; ++m) {
         const avae_modality& mo = c.mod[m];
         Mod md;
@@ -221,7 +238,7 @@ void plan_memory(avae_handle* h) {
             for (int k = 0; k < md.L; ++k) { md.dec.push_back(make_dense(b, pint, prev, md.hs[k], KU, es, false)); pflat += (size_t)(prev + 1) * md.hs[k]; prev = md.hs[k]; }
             md.outl = make_dense(b, pint, prev, md.n_in, KU, es, false);
             pflat += (size_t)(prev + 1) * md.n_in;
-            md.X0 = act_B(md.n_in, true);
+            md.X0 = stage_x0[m];
             for (int k = 0; k < md.L; ++k) md.E.push_back(act_B(md.hs[k], true));
             md.Z = act_B(nz, true);
             for (int k = 0; k < md.L; ++k) md.D.push_back(act_B(md.hs[k], true));
@@ -232,7 +249,7 @@ void plan_memory(avae_handle* h) {
         } else {
             const int R1 = md.hs[0], R2 = md.hs[1], G1 = mo.conv_gener[0], G2 = mo.conv_gener[1];
             md.L = 0;
-            md.X0 = act_B(md.n_in, false);
+            md.X0 = stage_x0[m];
             md.Z = act_B(nz, false);
             md.dH = act_B(2 * nz, false);
             md.dO = act_B(md.n_in, false);
@@ -272,7 +289,7 @@ void plan_memory(avae_handle* h) {
             for (int i = 1; i < 5; ++i) { const ConvStage& pv = md.cdec[i - 1]; src(md.cdec[i], pv.g.OH * pv.g.OW * pv.Y.ld, pv.Y.ld); }
         }
         md.ld32 = (int)rup(md.n_in, 8);      // multiple of the widest epilogue vector (8 elements)
-        md.X32 = b.take((size_t)B * md.ld32 * 4);
+        md.X32 = stage_x32[m];
         md.out32 = b.take((size_t)B * md.ld32 * 4);
         md.mulv = b.take((size_t)B * 2 * nz * 4);
         md.g0 = b.take((size_t)B * 3 * nz * 4);        // [g0mu | g0lv | dz/dlv factor]
@@ -284,7 +301,6 @@ void plan_memory(avae_handle* h) {
     h->off_m = b.take(pint * 4);
     h->off_v = b.take(pint * 4);
     h->off_g = b.take((pint + 64) * 4);      // + cost slot (element P_int), padded
-    h->off_eps = b.take((size_t)B * h->ld_eps * 4);
     // cost partial slots: one per output-loss tile (64-wide tiles bound the count) + latent tiles
     int slots = (B + kLatentRows - 1) / kLatentRows;
     for (int m = 0; m < h->M; ++m) slots += ((B + 63) / 64) * ((h->mods[m].n_in + 63) / 64);
@@ -502,8 +518,6 @@ struct Builder {
         return w;
     }
 };
-
-constexpr int kMultiSteps = 8;          // whole steps per replay of the multi-step graph
 
 inline bool is_gemm(int kind) { return kind <= K_WGRAD || kind == K_DGRAD_F32; }
 
@@ -884,7 +898,7 @@ void run_adam(avae_handle* h, int mode, hipStream_t s) {
 
 // stages the caller's batch (and eps) into the internal compute-dtype buffers
 PrepArgs make_prep_batch(avae_handle* h, const float* const* x, const int32_t* x_ld, const float* eps, int rows,
-                         unsigned long long salt) {
+                         unsigned long long salt, int n_steps = 1) {
     PrepArgs a;
     std::memset(&a, 0, sizeof(a));
     int base = 0;
@@ -903,6 +917,7 @@ PrepArgs make_prep_batch(avae_handle* h, const float* const* x, const int32_t* x
     a.eps_src = eps; a.eps_dst = h->at<float>(h->off_eps); a.eps_rows = rows; a.nz = h->nz; a.eps_ld = h->ld_eps;
     a.eps_blocks = (rows * ((h->nz + 3) / 4) + kThreads - 1) / kThreads;
     a.row_offset = h->cfg.row_offset; a.seed = h->cfg.seed; a.st = h->state(); a.stream_salt = salt;
+    a.n_steps = n_steps; a.blocks_per_step = a.total_tiles + a.eps_blocks; a.set_stride = (long long)h->stage_bytes;
     return a;
 }
 
@@ -934,6 +949,25 @@ void run_prep_single(avae_handle* h, const float* src, int src_ld, int rows, int
     launch_prep(h->cfg.compute_dtype, a, s);
 }
 
+// The same launch reading staging set j instead of set 0: every pointer into set 0 moves by j * stage_bytes.
+Launch relocated(const avae_handle* h, const Launch& L0, int j) {
+    if (j == 0) return L0;
+    Launch L = L0;
+    const unsigned char* lo = h->ws + h->stage_lo;
+    const unsigned char* hi = lo + h->stage_bytes;
+    const size_t delta = (size_t)j * h->stage_bytes;
+    auto fix = [&](auto& ptr) {
+        const unsigned char* q = reinterpret_cast<const unsigned char*>(ptr);
+        if (q >= lo && q < hi) ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(const_cast<unsigned char*>(q) + delta);
+    };
+    for (int i = 0; i < L.args.n_items && L.type == 0; ++i) {
+        WorkItem& w = L.args.items[i];
+        fix(w.A); fix(w.B); fix(w.out0); fix(w.out1); fix(w.out2); fix(w.aux0); fix(w.aux1); fix(w.aux2); fix(w.eps);
+    }
+    for (int i = 0; i < L.ga.n_seg && L.type == 1; ++i) fix(L.ga.seg[i].src);
+    return L;
+}
+
 hipGraphExec_t capture(avae_handle* h, const std::function<void(hipStream_t)>& body) {
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
@@ -945,55 +979,39 @@ hipGraphExec_t capture(avae_handle* h, const std::function<void(hipStream_t)>& b
     return ge;
 }
 
-// Same, for `reps` back-to-back copies of a step that starts with the input-staging kernel: keeps the template
-// graph and the staging node of every copy so the caller's pointers can be patched in before a replay
-// (hipGraphExecKernelNodeSetParams).  Stream capture of one stream gives a linear chain; the staging kernels are
-// every (chain length / reps)-th node of it.
-hipGraphExec_t capture_with_prep(avae_handle* h, int reps, const std::function<void(hipStream_t)>& body, hipGraph_t* graph_out,
-                                 std::vector<hipGraphNode_t>* prep_nodes) {
+// Same, for a graph whose first node is the input-staging kernel: keeps the template graph and that node so the
+// caller's pointers can be patched in before a replay (hipGraphExecKernelNodeSetParams).
+hipGraphExec_t capture_with_prep(avae_handle* h, const std::function<void(hipStream_t)>& body, hipGraph_t* graph_out,
+                                 hipGraphNode_t* prep_node) {
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     HIP_OK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-    try { for (int r = 0; r < reps; ++r) body(h->cap_stream); }
+    try { body(h->cap_stream); }
     catch (...) { (void)hipStreamEndCapture(h->cap_stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
     HIP_OK(hipStreamEndCapture(h->cap_stream, &g));
     try {
-        size_t n_nodes = 0, n_root = 0;
-        HIP_OK(hipGraphGetNodes(g, nullptr, &n_nodes));
+        size_t n_root = 0;
         HIP_OK(hipGraphGetRootNodes(g, nullptr, &n_root));
-        if (n_root != 1 || n_nodes == 0 || n_nodes % reps != 0) throw Err("internal error: captured step is not a chain of equal steps");
-        const size_t per_step = n_nodes / reps;
-        hipGraphNode_t node = nullptr;
-        HIP_OK(hipGraphGetRootNodes(g, &node, &n_root));
-        prep_nodes->clear();
-        for (size_t i = 0; i < n_nodes; ++i) {
-            if (i % per_step == 0) {
-                hipGraphNodeType ty;
-                HIP_OK(hipGraphNodeGetType(node, &ty));
-                if (ty != hipGraphNodeTypeKernel) throw Err("internal error: captured step does not start with the staging kernel");
-                prep_nodes->push_back(node);
-            }
-            if (i + 1 < n_nodes) {
-                size_t n_dep = 0;
-                HIP_OK(hipGraphNodeGetDependentNodes(node, nullptr, &n_dep));
-                if (n_dep != 1) throw Err("internal error: captured step is not a linear chain");
-                HIP_OK(hipGraphNodeGetDependentNodes(node, &node, &n_dep));
-            }
-        }
+        if (n_root != 1) throw Err("internal error: the captured step is not a chain");
+        HIP_OK(hipGraphGetRootNodes(g, prep_node, &n_root));
+        hipGraphNodeType ty;
+        HIP_OK(hipGraphNodeGetType(*prep_node, &ty));
+        if (ty != hipGraphNodeTypeKernel) throw Err("internal error: the captured step does not start with the staging kernel");
         HIP_OK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     } catch (...) { (void)hipGraphDestroy(g); throw; }
     *graph_out = g;
     return ge;
 }
 
-// Points one captured staging node at the caller's batch.
-void patch_prep(avae_handle* h, hipGraphExec_t ge, hipGraphNode_t node, const float* const* x, const int32_t* x_ld, const float* eps) {
-    PrepArgs a = make_prep_batch(h, x, x_ld, eps, h->B, 0x7261696eull);
+// Points one captured staging node at the caller's batch (or run of n_steps consecutive batches).
+void patch_prep(avae_handle* h, hipGraphExec_t ge, hipGraphNode_t node, const float* const* x, const int32_t* x_ld, const float* eps,
+                int n_steps = 1) {
+    PrepArgs a = make_prep_batch(h, x, x_ld, eps, h->B, 0x7261696eull, n_steps);
     void* kp[1] = {&a};
     hipKernelNodeParams np;
     std::memset(&np, 0, sizeof(np));
     np.func = const_cast<void*>(prep_kernel(h->cfg.compute_dtype));
-    np.gridDim = dim3(a.total_tiles + a.eps_blocks); np.blockDim = dim3(kThreads);
+    np.gridDim = dim3((a.total_tiles + a.eps_blocks) * n_steps); np.blockDim = dim3(kThreads);
     np.sharedMemBytes = 0; np.kernelParams = kp; np.extra = nullptr;
     HIP_OK(hipGraphExecKernelNodeSetParams(ge, node, &np));
 }
@@ -1009,7 +1027,11 @@ void init_device(avae_handle* h) {
     hipStream_t s = h->cap_stream;
     HIP_OK(hipMemsetAsync(h->ws, 0, h->ws_bytes, s));
     for (const Mod& md : h->mods) {
-        fill_ones(h, md.X0, s);
+        for (int j = 0; j < kMultiSteps; ++j) {       // every staging set carries its own constant-1 column
+            Act x = md.X0;
+            x.rm += (size_t)j * h->stage_bytes; x.tr += (size_t)j * h->stage_bytes;
+            fill_ones(h, x, s);
+        }
         for (const Act& a : md.E) fill_ones(h, a, s);
         fill_ones(h, md.Z, s);
         for (const Act& a : md.D) fill_ones(h, a, s);
@@ -1035,9 +1057,21 @@ void init_device(avae_handle* h) {
             run_launches(h, h->wgrad, cs, (int)(h->fwd.size() + h->bwd.size()));
             run_adam(h, 0, cs);
         };
-        h->g_full = capture_with_prep(h, 1, one_step, &h->g_full_graph, &h->g_full_prep);
-        // avae_train_steps: kMultiSteps whole steps per replay (a replay boundary costs ~5 us of idle GPU on this stack)
-        h->g_multi = capture_with_prep(h, kMultiSteps, one_step, &h->g_multi_graph, &h->g_multi_prep);
+        h->g_full = capture_with_prep(h, one_step, &h->g_full_graph, &h->g_full_prep);
+        // avae_train_steps: kMultiSteps whole steps per replay (a replay boundary costs ~5 us of idle GPU on this stack),
+        // their batches staged by ONE launch into the kMultiSteps staging sets; step j's launches read set j
+        h->g_multi = capture_with_prep(h, [&](hipStream_t cs) {
+            const PrepArgs a = make_prep_batch(h, x0.data(), nullptr, nullptr, h->B, 0x7261696eull, kMultiSteps);
+            launch_prep(h->cfg.compute_dtype, a, cs);
+            for (int j = 0; j < kMultiSteps; ++j) {
+                for (const std::vector<Launch>* ls : {&h->fwd, &h->bwd, &h->wgrad}) {
+                    std::vector<Launch> moved;
+                    for (const Launch& L : *ls) moved.push_back(relocated(h, L, j));
+                    run_launches(h, moved, cs);
+                }
+                run_adam(h, 0, cs);
+            }
+        }, &h->g_multi_graph, &h->g_multi_prep);
         h->g_eval = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, std::vector<Launch>{h->cost_only}, cs); });
         h->timing = tsave;
     }
@@ -1221,7 +1255,7 @@ int avae_step_apply(avae_handle* h, float* cost_host, void* stream) {
 // one single-replica step (Adam rides in the epilogue of the weight-gradient launches)
 void train_one(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, hipStream_t s) {
     if (h->g_full && !h->timing) {      // the whole step, staging kernel included, is one graph replay
-        patch_prep(h, h->g_full, h->g_full_prep[0], x_dev, x_ld, eps_dev);
+        patch_prep(h, h->g_full, h->g_full_prep, x_dev, x_ld, eps_dev);
         HIP_OK(hipGraphLaunch(h->g_full, s));
         return;
     }
@@ -1259,10 +1293,8 @@ int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev,
         int i = 0;
         if (h->g_multi && !h->timing)
             for (; i + kMultiSteps <= n_steps; i += kMultiSteps) {
-                for (int j = 0; j < kMultiSteps; ++j) {
-                    const float* e = batch(i + j);
-                    patch_prep(h, h->g_multi, h->g_multi_prep[j], x.data(), x_ld, e);
-                }
+                const float* e = batch(i);
+                patch_prep(h, h->g_multi, h->g_multi_prep, x.data(), x_ld, e, kMultiSteps);
                 HIP_OK(hipGraphLaunch(h->g_multi, s));
             }
         for (; i < n_steps; ++i) {

@@ -841,7 +841,10 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 template <typename CT>
 __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
     __shared__ float T[64][65];
-    const int bid = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int bstep = a.n_steps > 1 ? (int)blockIdx.x / a.blocks_per_step : 0;     // which of the batched steps
+    const int bid = (int)blockIdx.x - bstep * a.blocks_per_step;
+    const size_t set_off = (size_t)bstep * (size_t)a.set_stride;                      // bytes to that step's staging set
     if (bid >= a.total_tiles) {
         // eps: one quad of dims per thread; counter = (global row, quad, step lo, step hi ^ salt)
         if (!a.eps_dst) return;
@@ -852,9 +855,10 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
         float n[4];
         if (a.eps_src) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) n[e] = (4 * d4 + e < a.nz) ? a.eps_src[(size_t)row * a.nz + 4 * d4 + e] : 0.0f;   // caller's eps is dense [rows][n_z]
+            for (int e = 0; e < 4; ++e)      // caller's eps is dense [rows][n_z], batches back to back
+                n[e] = (4 * d4 + e < a.nz) ? a.eps_src[((size_t)bstep * a.eps_rows + row) * a.nz + 4 * d4 + e] : 0.0f;
         } else {
-            const unsigned long long step = (unsigned long long)a.st->step;
+            const unsigned long long step = (unsigned long long)a.st->step + (unsigned long long)bstep;
             unsigned r[4];
             philox4x32_10((unsigned)(a.row_offset + row), (unsigned)d4, (unsigned)step,
                           (unsigned)(step >> 32) ^ (unsigned)a.stream_salt,
@@ -867,9 +871,10 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
             n[0] = ra * __builtin_amdgcn_cosf(u1); n[1] = ra * __builtin_amdgcn_sinf(u1);
             n[2] = rb * __builtin_amdgcn_cosf(u3); n[3] = rb * __builtin_amdgcn_sinf(u3);
         }
+        float* eps_dst = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(a.eps_dst) + set_off);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (4 * d4 + e < a.nz) a.eps_dst[(size_t)row * a.eps_ld + 4 * d4 + e] = n[e];
+            if (4 * d4 + e < a.nz) eps_dst[(size_t)row * a.eps_ld + 4 * d4 + e] = n[e];
         return;
     }
     int it = 0;
@@ -879,6 +884,9 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
     const int tr = t / w.tiles_c, tc = t - tr * w.tiles_c;
     const int r0 = tr * 64, c0 = tc * 64;
     const int c4 = (tid & 15) * 4;
+    const float* src = w.src + (size_t)bstep * w.rows * w.src_ld;
+    float* dst32 = w.dst32 ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(w.dst32) + set_off) : nullptr;
+    CT* dstc = reinterpret_cast<CT*>(reinterpret_cast<unsigned char*>(w.dstc) + set_off);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (tid >> 4) + 16 * i;
@@ -887,10 +895,10 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
         if (grow < w.rows && gcol < w.cols) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (gcol + e < w.cols) v[e] = w.src[(size_t)grow * w.src_ld + gcol + e];
+                if (gcol + e < w.cols) v[e] = src[(size_t)grow * w.src_ld + gcol + e];
             const int nv = w.cols - gcol;
-            if (w.dst32) store_row<float>(w.dst32 + (size_t)grow * w.ld32 + gcol, v, nv);
-            store_row<CT>(reinterpret_cast<CT*>(w.dstc) + (size_t)grow * w.ldc + gcol, v, nv);
+            if (dst32) store_row<float>(dst32 + (size_t)grow * w.ld32 + gcol, v, nv);
+            store_row<CT>(dstc + (size_t)grow * w.ldc + gcol, v, nv);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) T[r][c4 + e] = v[e];
@@ -906,7 +914,7 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = T[r4 + e][c];
-            store_row<CT>(reinterpret_cast<CT*>(w.dstct) + (size_t)gcol * w.ldct + grow, v, w.rows - grow);
+            store_row<CT>(reinterpret_cast<CT*>(reinterpret_cast<unsigned char*>(w.dstct) + set_off) + (size_t)gcol * w.ldct + grow, v, w.rows - grow);
         }
     }
 }
@@ -916,7 +924,7 @@ const void* prep_kernel(int compute_dtype) {
 }
 
 void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s) {
-    const int n_blocks = a.total_tiles + a.eps_blocks;
+    const int n_blocks = (a.total_tiles + a.eps_blocks) * (a.n_steps > 1 ? a.n_steps : 1);
     if (n_blocks <= 0) return;
     if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_prep<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
     else AVAE_LAUNCH((k_prep<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
