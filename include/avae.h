@@ -112,9 +112,10 @@ int avae_train_step(avae_handle* h, const float* const* x_dev, const int32_t* x_
 /* The inner batch loop of train() (vae_assoc.py:541-550 over DataSet.next_batch's consecutive slices,
  * dataset.py:22-43) as ONE submission: exactly n_steps successive avae_train_step calls, step i on rows
  * [i*batch_size, (i+1)*batch_size) of every x_dev[m] (row stride x_ld[m]) and of eps_dev (dense [.., n_z];
- * NULL -> internal generator).  Steps are replayed eight to a hipGraph, so the host is out of the loop and
- * the per-replay boundary is paid once per eight steps.  cost_host (optional) receives the LAST step's cost;
- * every step's cost is in avae_cost_history. */
+ * NULL -> internal generator).  Steps are replayed sixteen (then four) to a hipGraph whose first kernel stages
+ * all of the replay's batches at once, so the host is out of the loop and the replay boundary and the staging
+ * launch are paid once per sixteen steps.  cost_host (optional) receives the LAST step's cost; every step's
+ * cost is in avae_cost_history. */
 int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev, const int32_t* x_ld,
                      const float* eps_dev, float* cost_host, void* stream);
 /* The same step cut at the data-parallel seam: backward leaves the local gradient (internal

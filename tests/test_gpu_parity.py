@@ -271,11 +271,11 @@ def test_graph_replay_equals_eager(V):
 
 @pytest.mark.parametrize("given_eps", [False, True])
 def test_train_steps_equals_single_steps(V, given_eps):
-    """avae_train_steps (runs of 8 steps per graph replay, staging nodes re-pointed per replay while earlier
+    """avae_train_steps (16 or 4 steps per graph replay, all their batches staged by one launch, re-pointed while earlier
     replays are still in flight) is exactly n successive avae_train_step calls: bitwise equal costs and weights."""
     archs = [make_arch("image", 784, 64, 48, 8), make_arch("joint", 147, 40, 32, 8)]
     rng = np.random.default_rng(9)
-    n, B = 21, 32                                          # 2 replays of 8 + 5 single steps
+    n, B = 21, 32                                          # one replay of 16 steps, one of 4, one single step
     data = np.concatenate(synth_batch(rng, n * B, [784, 147], [True, False]), axis=1)
     dev = torch.as_tensor(data).cuda()
     X = [dev[:, :784], dev[:, 784:]]                       # column slices of one matrix: row stride 931

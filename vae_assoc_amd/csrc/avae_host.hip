@@ -31,7 +31,8 @@ struct Err : std::runtime_error { using std::runtime_error::runtime_error; };
                       std::to_string(__LINE__) + ")");                                           \
     } while (0)
 
-constexpr int kMultiSteps = 8;          // whole steps per replay of the multi-step graph (avae_train_steps)
+constexpr int kMultiSteps = 16;         // most whole steps per replay of a multi-step graph (avae_train_steps) = staging sets
+constexpr int kMultiSizes[2] = {16, 4};  // captured replay lengths: a run of n batches goes 16,16,...,4,4,...,1,1
 
 inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -129,9 +130,9 @@ struct avae_handle {
     std::vector<Inf> inf_enc, inf_dec;
 
     hipGraphExec_t g_full = nullptr, g_bwd = nullptr, g_eval = nullptr;
-    hipGraphExec_t g_multi = nullptr;       // kMultiSteps whole steps (avae_train_steps)
-    hipGraph_t g_full_graph = nullptr, g_multi_graph = nullptr;   // templates, kept: their staging-kernel nodes are re-parameterised per replay
-    hipGraphNode_t g_full_prep = nullptr, g_multi_prep = nullptr;
+    hipGraphExec_t g_multi[2] = {nullptr, nullptr};   // kMultiSizes[i] whole steps per replay (avae_train_steps)
+    hipGraph_t g_full_graph = nullptr, g_multi_graph[2] = {nullptr, nullptr};   // templates, kept: their staging-kernel nodes are re-parameterised per replay
+    hipGraphNode_t g_full_prep = nullptr, g_multi_prep[2] = {nullptr, nullptr};
 
     bool timing = false;
     bool debug_sync = false;
@@ -1060,10 +1061,10 @@ void init_device(avae_handle* h) {
         h->g_full = capture_with_prep(h, one_step, &h->g_full_graph, &h->g_full_prep);
         // avae_train_steps: kMultiSteps whole steps per replay (a replay boundary costs ~5 us of idle GPU on this stack),
         // their batches staged by ONE launch into the kMultiSteps staging sets; step j's launches read set j
-        h->g_multi = capture_with_prep(h, [&](hipStream_t cs) {
-            const PrepArgs a = make_prep_batch(h, x0.data(), nullptr, nullptr, h->B, 0x7261696eull, kMultiSteps);
+        for (int gi = 0; gi < 2; ++gi) h->g_multi[gi] = capture_with_prep(h, [&](hipStream_t cs) {
+            const PrepArgs a = make_prep_batch(h, x0.data(), nullptr, nullptr, h->B, 0x7261696eull, kMultiSizes[gi]);
             launch_prep(h->cfg.compute_dtype, a, cs);
-            for (int j = 0; j < kMultiSteps; ++j) {
+            for (int j = 0; j < kMultiSizes[gi]; ++j) {
                 for (const std::vector<Launch>* ls : {&h->fwd, &h->bwd, &h->wgrad}) {
                     std::vector<Launch> moved;
                     for (const Launch& L : *ls) moved.push_back(relocated(h, L, j));
@@ -1071,7 +1072,7 @@ void init_device(avae_handle* h) {
                 }
                 run_adam(h, 0, cs);
             }
-        }, &h->g_multi_graph, &h->g_multi_prep);
+        }, &h->g_multi_graph[gi], &h->g_multi_prep[gi]);
         h->g_eval = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, std::vector<Launch>{h->cost_only}, cs); });
         h->timing = tsave;
     }
@@ -1182,8 +1183,8 @@ void avae_destroy(avae_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
-    for (hipGraphExec_t g : {h->g_full, h->g_multi, h->g_bwd, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
-    for (hipGraph_t g : {h->g_full_graph, h->g_multi_graph}) if (g) (void)hipGraphDestroy(g);
+    for (hipGraphExec_t g : {h->g_full, h->g_multi[0], h->g_multi[1], h->g_bwd, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
+    for (hipGraph_t g : {h->g_full_graph, h->g_multi_graph[0], h->g_multi_graph[1]}) if (g) (void)hipGraphDestroy(g);
     for (TimingRec& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->own_ws && h->ws) (void)hipFree(h->ws);
@@ -1291,11 +1292,11 @@ int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev,
             return eps_dev ? eps_dev + (size_t)i * h->B * h->nz : nullptr;
         };
         int i = 0;
-        if (h->g_multi && !h->timing)
-            for (; i + kMultiSteps <= n_steps; i += kMultiSteps) {
+        for (int gi = 0; gi < 2 && !h->timing; ++gi)
+            for (; h->g_multi[gi] && i + kMultiSizes[gi] <= n_steps; i += kMultiSizes[gi]) {
                 const float* e = batch(i);
-                patch_prep(h, h->g_multi, h->g_multi_prep, x.data(), x_ld, e, kMultiSteps);
-                HIP_OK(hipGraphLaunch(h->g_multi, s));
+                patch_prep(h, h->g_multi[gi], h->g_multi_prep[gi], x.data(), x_ld, e, kMultiSizes[gi]);
+                HIP_OK(hipGraphLaunch(h->g_multi[gi], s));
             }
         for (; i < n_steps; ++i) {
             const float* e = batch(i);
