@@ -578,18 +578,30 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
         float* Zs = Cs + BM * LDC;                         // second fp32 tile: z
         const float* eps = reinterpret_cast<const float*>(w.aux0);
         if (w.out1) {
-            constexpr int NI = 8;                           // elements per thread handled together
-            for (int i0 = tid; i0 < BM * nz; i0 += NI * kThreads) {
-                float ev[NI];
+            // z = mu + exp(lv/2) * eps: four latent dims per thread and chunk, every eps read in flight before the first
+            // use, no division inside the loops (chunk c = tid + k*256 -> (row, quad) by stepping)
+            const int QE = w.ldx >> 2;                      // eps row = QE quads (ldx = roundup(n_z, 4))
+            constexpr int NCK = BM * 16 / kThreads;          // n_z <= 64 -> QE <= 16 -> at most BM*16 chunks
+            const int drow = kThreads / QE, dq = kThreads - drow * QE;
+            int row = tid / QE, q = tid - row * QE;
+            f32x4 ev[NCK];
+            int rws[NCK], qs[NCK];
 #pragma unroll
-                for (int q = 0; q < NI; ++q) {
-                    const int idx = i0 + q * kThreads, row = idx / nz, d = idx - row * nz;
-                    ev[q] = (idx < BM * nz) ? eps[(size_t)min(m0 + row, M - 1) * w.ldx + d] : 0.0f;
-                }
+            for (int k = 0; k < NCK; ++k) {
+                rws[k] = row; qs[k] = q;
+                ev[k] = *reinterpret_cast<const f32x4*>(eps + (size_t)min(m0 + min(row, BM - 1), M - 1) * w.ldx + 4 * q);
+                row += drow; q += dq;
+                if (q >= QE) { q -= QE; ++row; }
+            }
 #pragma unroll
-                for (int q = 0; q < NI; ++q) {
-                    const int idx = i0 + q * kThreads, row = idx / nz, d = idx - row * nz;
-                    if (idx < BM * nz) Zs[cs_idx<LDC>(row, d)] = Cs[cs_idx<LDC>(row, d)] + fexp(0.5f * Cs[cs_idx<LDC>(row, nz + d)]) * ev[q];
+            for (int k = 0; k < NCK; ++k) {
+                if (rws[k] < BM) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int d = 4 * qs[k] + e;
+                        if (d < nz)
+                            Zs[cs_idx<LDC>(rws[k], d)] = Cs[cs_idx<LDC>(rws[k], d)] + fexp(0.5f * Cs[cs_idx<LDC>(rws[k], nz + d)]) * ev[k][e];
+                    }
                 }
             }
         }
