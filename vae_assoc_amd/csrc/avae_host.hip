@@ -293,7 +293,7 @@ void plan_memory(avae_handle* h) {
         md.X32 = stage_x32[m];
         md.out32 = b.take((size_t)B * md.ld32 * 4);
         md.mulv = b.take((size_t)B * 2 * nz * 4);
-        md.g0 = b.take((size_t)B * 3 * nz * 4);        // [g0mu | g0lv | dz/dlv factor]
+        md.g0 = b.take((size_t)B * 3 * h->ld_eps * 4);  // [g0mu | g0lv | dz/dlv factor], each roundup(n_z, 4) wide
         h->mods.push_back(std::move(md));
     }
     h->P_int = pint;
@@ -1522,7 +1522,7 @@ int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t m
             const bool g0 = n[0] == 'g';
             const int m = std::atoi(n.c_str() + (g0 ? 3 : 4));
             if (m < 0 || m >= h->M) throw Err("debug_fetch: modality out of range");
-            src = h->at<void>(g0 ? h->mods[m].g0 : h->mods[m].mulv); cnt = (size_t)h->B * (g0 ? 3 : 2) * h->nz;
+            src = h->at<void>(g0 ? h->mods[m].g0 : h->mods[m].mulv); cnt = g0 ? (size_t)h->B * 3 * h->ld_eps : (size_t)h->B * 2 * h->nz;
         } else throw Err("debug_fetch: unknown tensor " + n);
         if (cnt > max_floats) throw Err("debug_fetch: destination too small");
         HIP_OK(hipDeviceSynchronize());

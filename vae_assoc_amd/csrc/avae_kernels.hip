@@ -312,10 +312,10 @@ __device__ __forceinline__ void latent_item(const WorkItem& w, int t, float* red
 #pragma unroll
         for (int m = 0; m < kMaxMod; ++m) {
             if (m < w.n_mod) {
-                g0[m][(size_t)grow * 3 * nz + d] = gmu[m];
-                g0[m][(size_t)grow * 3 * nz + nz + d] = glv[m];
+                g0[m][(size_t)grow * 3 * w.ldx + d] = gmu[m];                 // row = [g0mu | g0lv | F], each ldx = roundup(n_z, 4) wide
+                g0[m][(size_t)grow * 3 * w.ldx + w.ldx + d] = glv[m];
                 // reparameterisation factor for the backward pass: d z / d lv = 1/2 exp(lv/2) eps
-                g0[m][(size_t)grow * 3 * nz + 2 * nz + d] = 0.5f * eps_v * fexp(0.5f * lv[m]);
+                g0[m][(size_t)grow * 3 * w.ldx + 2 * w.ldx + d] = 0.5f * eps_v * fexp(0.5f * lv[m]);
             }
         }
     }
@@ -678,23 +678,38 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
         float* Zs = Cs + BM * LDC;
         const float* g0 = reinterpret_cast<const float*>(w.aux2);
         {
-            constexpr int NI = 8;
-            for (int i0 = tid; i0 < BM * nz; i0 += NI * kThreads) {
-                float gm[NI], gl[NI], gf[NI];
+            // four latent dims per thread and chunk, all g0 reads in flight before the first use, no division in the loops
+            const int lde = (nz + 3) & ~3, QE = lde >> 2;   // g0 row = [g0mu | g0lv | F], each lde = roundup(n_z, 4) wide
+            constexpr int NCK = BM * 16 / kThreads;          // n_z <= 64 -> QE <= 16 -> at most BM*16 chunks
+            const int drow = kThreads / QE, dq = kThreads - drow * QE;
+            int row = tid / QE, q = tid - row * QE;
+            constexpr int HALF = NCK > 4 ? NCK / 2 : NCK;    // two batches on the 128-row tile: 3 x 4 quads in flight each
 #pragma unroll
-                for (int q = 0; q < NI; ++q) {
-                    const int idx = i0 + q * kThreads, row = idx / nz, d = idx - row * nz;
-                    const size_t o = (size_t)min(m0 + row, M - 1) * 3 * nz + d;
-                    const bool ok = idx < BM * nz;
-                    gm[q] = ok ? g0[o] : 0.0f; gl[q] = ok ? g0[o + nz] : 0.0f; gf[q] = ok ? g0[o + 2 * nz] : 0.0f;
+            for (int k0 = 0; k0 < NCK; k0 += HALF) {
+                f32x4 gm[HALF], gl[HALF], gf[HALF];
+                int rws[HALF], qs[HALF];
+#pragma unroll
+                for (int k = 0; k < HALF; ++k) {
+                    rws[k] = row; qs[k] = q;
+                    const float* gr = g0 + (size_t)min(m0 + min(row, BM - 1), M - 1) * 3 * lde + 4 * q;
+                    gm[k] = *reinterpret_cast<const f32x4*>(gr);
+                    gl[k] = *reinterpret_cast<const f32x4*>(gr + lde);
+                    gf[k] = *reinterpret_cast<const f32x4*>(gr + 2 * lde);
+                    row += drow; q += dq;
+                    if (q >= QE) { q -= QE; ++row; }
                 }
 #pragma unroll
-                for (int q = 0; q < NI; ++q) {
-                    const int idx = i0 + q * kThreads, row = idx / nz, d = idx - row * nz;
-                    if (idx < BM * nz) {
-                        const float dz = Cs[cs_idx<LDC>(row, d)];
-                        Zs[cs_idx<LDC>(row, d)] = dz + gm[q];
-                        Zs[cs_idx<LDC>(row, nz + d)] = dz * gf[q] + gl[q];
+                for (int k = 0; k < HALF; ++k) {
+                    if (rws[k] < BM) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int d = 4 * qs[k] + e;
+                            if (d < nz) {
+                                const float dz = Cs[cs_idx<LDC>(rws[k], d)];
+                                Zs[cs_idx<LDC>(rws[k], d)] = dz + gm[k][e];
+                                Zs[cs_idx<LDC>(rws[k], nz + d)] = dz * gf[k][e] + gl[k][e];
+                            }
+                        }
                     }
                 }
             }
@@ -1049,8 +1064,9 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
                     }
                 }
                 if (latent) {        // dmu = dz + g0mu ; dlv = dz * F + g0lv   (g0 = [g0mu | g0lv | F], reparameterisation)
-                    const float* gr = w.g0 + (size_t)pix * 3 * w.nz;
-                    acc = col < w.nz ? acc + gr[ci] : acc * gr[2 * w.nz + ci] + gr[w.nz + ci];
+                    const int lde = (w.nz + 3) & ~3;                      // g0 row = [g0mu | g0lv | F], each roundup(n_z, 4) wide
+                    const float* gr = w.g0 + (size_t)pix * 3 * lde;
+                    acc = col < w.nz ? acc + gr[ci] : acc * gr[2 * lde + ci] + gr[lde + ci];
                 } else if (w.yprev) {
                     acc *= act_bwd(w.act, ct_load<CT>(reinterpret_cast<const CT*>(w.yprev) + (size_t)pix * w.ldy + ci));
                 }
