@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: paired-samples/sec of the img+jnt assoc-VAE train step on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4|c1] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c4|c5] [--no-cpu-baseline]
 
 A "step" is one pass of the hot path (input staging, forward, fused losses, backward,
 [gradient all-reduce], Adam + shadow refresh) over one batch of synthetic paired samples that is
@@ -43,14 +43,30 @@ CONFIGS = {
            "C2 img+jnt assoc-VAE 784-500-500/147-200-200 n_z=20 batch=256/GPU bf16"),
     "c4": ([arch("image", 784, [1024] * 4, 64), arch("joint", 147, [1024] * 4, 64)], 4096, "bf16",
            "C4 4x1024 MLP enc/dec n_z=64 batch=4096 bf16 (MFMA stress)"),
+    "c5": ([arch("image", 784, [500, 500], 20), arch("joint", 147, [200, 200], 20), arch("aux", 256, [200, 200], 20)], 256, "fp32",
+           "C5 img+jnt+aux(256) assoc-VAE n_z=20 batch=256/GPU fp32"),
 }
 HYPER = dict(binary=[True, False], weights=[50.0, 1.0], assoc_lambda=8.0, learning_rate=1e-3)   # script values
 
 
-def synth(rng, rows):
-    """SURVEY.md 8d synthetic inputs: stroke-like images in [0,1] (70 % dark), z-scored joint features."""
+def hyper_for(archs):
+    """Script hyper-parameters, extended with Gaussian weight-1 entries for modalities beyond image + joint (C5's aux)."""
+    extra = len(archs) - 2
+    return dict(HYPER, binary=HYPER["binary"] + [False] * extra, weights=HYPER["weights"] + [1.0] * extra)
+
+
+def synth_for(rng, archs, rows):
+    cols = synth(rng, rows, n_aux=archs[2]["n_input"] if len(archs) > 2 else 0)
+    return np.concatenate(cols, axis=1), np.concatenate([[0], np.cumsum([a["n_input"] for a in archs])])
+
+
+def synth(rng, rows, n_aux=0):
+    """SURVEY.md 8d synthetic inputs: stroke-like images in [0,1] (70 % dark), z-scored joint features (and a z-scored
+    aux modality for C5)."""
     img = (np.clip(rng.beta(0.25, 1.5, size=(rows, 784)), 0, 1) * (rng.random((rows, 784)) >= 0.7)).astype(np.float32)
     jnt = rng.standard_normal((rows, 147)).astype(np.float32)
+    if n_aux:
+        return img, jnt, rng.standard_normal((rows, n_aux)).astype(np.float32)
     return img, jnt
 
 
@@ -127,14 +143,16 @@ def cpu_baseline(archs, B, budget_s=12.0):
     host cores on a bounded sample of the same workload."""
     from oracle import vae_assoc_oracle as O
     rng = np.random.default_rng(20260104)
-    img, jnt = synth(rng, B)
+    mat, edges = synth_for(rng, archs, B)
+    X = [mat[:, edges[k]:edges[k + 1]] for k in range(len(archs))]
     eps = rng.standard_normal((B, archs[0]["n_z"])).astype(np.float32)
-    m = O.OracleAssocVAE(archs, HYPER["binary"], "relu", HYPER["weights"], HYPER["assoc_lambda"], HYPER["learning_rate"], B,
+    hp = hyper_for(archs)
+    m = O.OracleAssocVAE(archs, hp["binary"], "relu", hp["weights"], hp["assoc_lambda"], hp["learning_rate"], B,
                          dtype=np.float32, seed=0)
-    m.partial_fit([img, jnt], eps)                # warm-up
+    m.partial_fit(X, eps)                # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        m.partial_fit([img, jnt], eps)
+        m.partial_fit(X, eps)
         n += 1
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 2000:
@@ -181,20 +199,21 @@ def main():
     dtype = args.dtype or dtype
     es = 2 if dtype == "bf16" else 4
     model = AssocVariationalAutoEncoder(archs, transfer_fct="relu", batch_size=B, compute_dtype=dtype, device=local_rank,
-                                        seed=0, use_graph=not args.no_graph, data_parallel=world > 1, **HYPER)
+                                        seed=0, use_graph=not args.no_graph, data_parallel=world > 1, **hyper_for(archs))
     # resident synthetic data: 16 batches per rank (rank r owns global rows [r*B, (r+1)*B) of each global batch)
     nb = 16
     rng = np.random.default_rng(20260104 + rank)
-    img, jnt = synth(rng, nb * B)
-    data = torch.as_tensor(np.concatenate([img, jnt], axis=1)).cuda()           # [nb*B, 931], split by pointer + stride
-    batches = [[data[i * B:(i + 1) * B, :784], data[i * B:(i + 1) * B, 784:]] for i in range(nb)]
+    mat, edges = synth_for(rng, archs, nb * B)
+    data = torch.as_tensor(mat).cuda()                                           # [nb*B, 931], split by pointer + stride
+    n_mod = len(archs)
+    batches = [[data[i * B:(i + 1) * B, edges[k]:edges[k + 1]] for k in range(n_mod)] for i in range(nb)]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    whole = [data[:, :784], data[:, 784:]]
+    whole = [data[:, edges[k]:edges[k + 1]] for k in range(n_mod)]
 
     def run(n):
         """n train steps over the resident batches in order (eps: in-kernel Philox stream).  A single replica

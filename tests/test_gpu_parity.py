@@ -194,6 +194,14 @@ def test_bench_config_c2_bf16(V):
 
 
 # ----------------------------------------------------------------------------- shapes / options
+@pytest.mark.parametrize("lam", [0.0, 1e-5, 1e-2, 1.0, 8.0, 50.0])
+def test_config_c5_three_modalities_lambda_sweep(V, lam):
+    """BASELINE.json configs[4]: img + jnt + 256-d aux, fp32, association weight swept over the values the reference's
+    callers use (train default 1e-5 vae_assoc.py:498, script 8, robot app 50) -- per-GPU shard of 256 rows."""
+    archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20), make_arch("aux", 256, 200, 200, 20)]
+    check_step_parity(V, archs, [True, False, False], [50.0, 1.0, 1.0], lam, "relu", 256, "fp32", steps=1)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [
     dict(archs=[make_arch("a", 60, 20, 16, 5), make_arch("b", 21, 12, 10, 5)], binary=[True, False], w=[50.0, 1.0], lam=8.0, act="relu", B=9),

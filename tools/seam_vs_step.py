@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""C4: fused wgrad+Adam step (avae_train_step) vs plain wgrad + k_adam (avae_step_backward + avae_step_apply)."""
+"""One submission per step (avae_train_step) vs the data-parallel seam (avae_step_backward + avae_step_apply) on one GPU."""
 import os
 import sys
 import time
@@ -19,16 +19,16 @@ img, jnt = bench.synth(rng, 4 * B)
 data = torch.as_tensor(np.concatenate([img, jnt], axis=1)).cuda()
 batches = [[data[i * B:(i + 1) * B, :784], data[i * B:(i + 1) * B, 784:]] for i in range(4)]
 n = 200 if cfg == "c4" else 2000
-for mode in ("fused", "unfused", "fused", "unfused"):
+for mode in ("step", "seam", "step", "seam"):
     for i in range(20):
-        if mode == "fused":
+        if mode == "step":
             model.partial_fit(batches[i % 4], return_cost=False)
         else:
             model._backward(batches[i % 4]); model._apply(False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
-        if mode == "fused":
+        if mode == "step":
             model.partial_fit(batches[i % 4], return_cost=False)
         else:
             model._backward(batches[i % 4]); model._apply(False)
