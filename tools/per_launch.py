@@ -4,10 +4,10 @@
   python tools/per_launch.py <kernel_trace.csv> <names.json|bench-json-line> > profiles/rNN_<cfg>_per_launch.json
 
 k_grouped runs every GEMM launch of the step, so rocprofv3's per-kernel-name statistics lump them
-together.  A graph replay issues the launches in a fixed order (k_prep, then the launches in the order
-bench.py's `kernels_us` names them in the plan: fwd_*, bwd_*, wgrad*), so the n-th dispatch after a
-k_prep is the n-th launch of the plan.  Steps whose dispatch count differs (warm-up, the eager timing
-pass) are skipped.
+together.  A graph replay issues the launches in a fixed order (fwd_*, bwd_*, wgrad*, adam), so the n-th
+dispatch after a k_adam is the n-th launch of the plan; the staging kernel k_prep runs once per replay
+(16 or 4 steps) or once per single step and is reported on its own.  Steps whose dispatch count differs are
+skipped.
 """
 import csv
 import json
@@ -19,32 +19,39 @@ ORDER_HINT = ["fwd_enc", "conv_enc", "conv_head", "fwd_head", "fwd_dec", "conv_d
 
 def main():
     trace, order_file = sys.argv[1], sys.argv[2]
-    names = json.load(open(order_file))["order"]
-    rows = [r for r in csv.DictReader(open(trace)) if "k_prep" in r["Kernel_Name"] or "k_grouped" in r["Kernel_Name"]
-            or "k_gather" in r["Kernel_Name"] or "k_col2im" in r["Kernel_Name"] or "k_adam" in r["Kernel_Name"]]
+    names = json.load(open(order_file))["order"]          # launches of one step in order, ending with "adam"
+    rows = [r for r in csv.DictReader(open(trace)) if any(k in r["Kernel_Name"] for k in ("k_prep", "k_grouped", "k_gather", "k_col2im", "k_adam"))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))            # the CSV is not in execution order
-    steps, cur = [], None
+    # a step ends with k_adam; the staging kernel k_prep runs once per step or once per replay of 16 / 4 steps
+    steps, cur, preps = [], [], []
     for r in rows:
         if "k_prep" in r["Kernel_Name"]:
-            if cur is not None:
-                steps.append(cur)
-            cur = [r]
-        elif cur is not None:
-            cur.append(r)
-    if cur:
-        steps.append(cur)
-    steps = [s for s in steps if len(s) == len(names) + 1]
+            preps.append(r)
+            continue
+        cur.append(r)
+        if "k_adam" in r["Kernel_Name"]:
+            steps.append(cur)
+            cur = []
+    steps = [s for s in steps if len(s) == len(names)]
     steps = steps[len(steps) // 5:]                      # drop the first fifth (warm-up)
+    preps = preps[len(preps) // 5:]
+
+    def dur(r):
+        return (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+
+    def wgs(r):
+        return (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])) * (int(r["Grid_Size_Y"]) // int(r["Workgroup_Size_Y"]))
     out = {}
-    for j, name in enumerate(["prep"] + names):
-        d = [(int(s[j]["End_Timestamp"]) - int(s[j]["Start_Timestamp"])) / 1e3 for s in steps]
-        out[name] = {"calls": len(d), "avg_us": round(sum(d) / len(d), 2), "min_us": round(min(d), 2),
-                     "workgroups": (int(steps[0][j]["Grid_Size_X"]) // int(steps[0][j]["Workgroup_Size_X"]))
-                                   * (int(steps[0][j]["Grid_Size_Y"]) // int(steps[0][j]["Workgroup_Size_Y"]))}
-    span = [(int(s[-1]["End_Timestamp"]) - int(s[0]["Start_Timestamp"])) / 1e3 for s in steps]
-    print(json.dumps({"source": "rocprofv3 --kernel-trace, %d graph-replayed steps" % len(steps),
-                      "launches": out, "sum_avg_us": round(sum(v["avg_us"] for v in out.values()), 2),
-                      "step_span_avg_us": round(sum(span) / len(span), 2)}, indent=1))
+    for j, name in enumerate(names):
+        d = [dur(s[j]) for s in steps]
+        out[name] = {"calls": len(d), "avg_us": round(sum(d) / len(d), 2), "min_us": round(min(d), 2), "workgroups": wgs(steps[0][j])}
+    pd = [dur(r) for r in preps]
+    # both lists lost their first fifth, so their ratio is the number of steps one staging launch serves
+    prep = {"calls": len(pd), "avg_us": round(sum(pd) / len(pd), 2), "min_us": round(min(pd), 2),
+            "workgroups": max(wgs(r) for r in preps), "steps_per_call": round(len(steps) / len(pd), 1),
+            "avg_us_per_step": round(sum(pd) / len(steps), 2)}
+    print(json.dumps({"source": "rocprofv3 --kernel-trace, %d graph-replayed steps" % len(steps), "prep": prep,
+                      "launches": out, "sum_avg_us": round(sum(v["avg_us"] for v in out.values()) + prep["avg_us_per_step"], 2)}, indent=1))
 
 
 if __name__ == "__main__":
