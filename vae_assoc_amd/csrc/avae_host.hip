@@ -658,11 +658,9 @@ void build_training_plan(avae_handle* h) {
         // needed by bwd_dec1_latent; they ride here so that the decoder's hidden launches stay plain GEMM launches
         h->items.push_back(bd.latent());
     });
-    // ---- backward: the dgrad chain (one launch per layer, all modalities), then EVERY weight
-    // gradient in one final wave of launches: they depend only on stored activations / activation
-    // gradients, and being last lets the single-replica path fuse Adam + shadow refresh into their
-    // epilogues (no launch reads a weight shadow afterwards, so updating in place is hazard-free).
-    // Conv stages go GEMM (fp32 patch gradients) -> k_col2im (sum + act' -> gradient of the producing stage).
+    // ---- backward: the dgrad chain (one launch per layer, all modalities), then EVERY weight gradient in the last
+    // launch(es), then k_adam.  Conv stages go GEMM (fp32 patch gradients) -> k_col2im (sum + act' -> gradient of the
+    // producing stage).
     group("bwd_out", h->bwd, [&] {
         for (Mod& md : h->mods) {
             if (md.conv) h->items.push_back(bd.conv_dgrad(md.cdec[4], md.dO));
@@ -1253,7 +1251,7 @@ int avae_step_apply(avae_handle* h, float* cost_host, void* stream) {
     });
 }
 
-// one single-replica step (Adam rides in the epilogue of the weight-gradient launches)
+// one single-replica step
 void train_one(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, hipStream_t s) {
     if (h->g_full && !h->timing) {      // the whole step, staging kernel included, is one graph replay
         patch_prep(h, h->g_full, h->g_full_prep, x_dev, x_ld, eps_dev);
