@@ -10,12 +10,12 @@
 // The bias is the last row of W_aug and every activation carries a constant-1 column, so the
 // bias add and the bias gradient fall out of the same MFMA products.
 //
-// Per 256-thread workgroup: a BM x BN output tile (64x64 or 128x128), 4 wave64s in a 2x2
-// arrangement, v_mfma_f32_16x16x32_bf16 (bf16 operands) or v_mfma_f32_16x16x4_f32 (exact fp32),
-// fp32 accumulation in registers, a 4-stage LDS-DMA ring (global_load_lds_dwordx4, XOR-swizzled
-// 128-byte rows: conflict-free ds_read_b128, up to 3 K tiles in flight), and an LDS-staged
-// epilogue that fuses the activation / reparameterisation / loss / gradient maths and writes both
-// the row-major and the transposed result with coalesced vector stores.
+// Per workgroup: a BM x BN output tile -- 64x64 or 128x128 with 4 wave64s (2x2), or 256x128 with 8 wave64s (4x2) --
+// v_mfma_f32_16x16x32_bf16 (bf16 operands) or v_mfma_f32_16x16x4_f32 (exact fp32), fp32 accumulation in
+// registers, a 4- / 2- / 3-stage LDS-DMA ring (global_load_lds_dwordx4, XOR-swizzled 128-byte rows:
+// conflict-free ds_read_b128, up to RING-1 K tiles in flight), and an LDS-staged epilogue that fuses the
+// activation / reparameterisation / loss / gradient maths and writes both the row-major and the transposed
+// result with coalesced vector stores.  What bounds the loop and why the tiles are what they are: DESIGN.md, section 4.
 //
 // Reference maths: /root/reference/vae_assoc.py:163-222 (encoder), :243-304 (decoder),
 // :306-371 (losses), :373-374 (Adam); restated for CPU in oracle/vae_assoc_oracle.py.
