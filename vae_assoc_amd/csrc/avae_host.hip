@@ -92,6 +92,7 @@ struct Launch {
     int type = 0;          // 0: grouped GEMM kernel, 1: k_gather (im2col), 2: k_col2im
     int cfg = 0, first = 0, count = 0, blocks = 0, lds = 0;
     int grid_x = 1, grid_y = 1;   // grouped kernel: tile slot x item
+    bool tn = false;              // K-major operands (the weight-gradient launches)
     LaunchArgs args{};
     GatherArgs ga{};
     Col2imArgs ca{};
@@ -488,8 +489,10 @@ struct Builder {
         c.tiles_r = (R + 63) / 64; c.tiles_c = (C + 63) / 64;
         return c;
     }
+    // dW_aug[m][n] = sum_k X_aug[k][m] * dA[k][n]: both operands are read as stored (row = sample k), see the K-major
+    // ("TN") images in avae_kernels.hip; rows >= batch of either buffer are zero padding
     WorkItem wgrad(const Act& x, const Dense& d, const Act& dA) {
-        WorkItem w = gemm_item(K_WGRAD, d.in + 1, d.out, K_of(x.rows), p<void>(x.tr), x.ldT, p<void>(dA.tr), dA.ldT);
+        WorkItem w = gemm_item(K_WGRAD, d.in + 1, d.out, K_of(x.rows), p<void>(x.rm), x.ld, p<void>(dA.rm), dA.ld);
         w.out0 = h->grad() + d.master; w.ld0 = d.ld;
         return w;
     }
@@ -741,9 +744,11 @@ void build_training_plan(avae_handle* h) {
         } else {
             chunk_up(wg);
         }
-        for (size_t c = 0; c < chunks.size(); ++c)
+        for (size_t c = 0; c < chunks.size(); ++c) {
             group("wgrad" + (chunks.size() > 1 ? std::to_string(c + 1) : std::string()), h->wgrad,
                   [&] { for (const WorkItem& w : chunks[c]) h->items.push_back(w); });
+            h->wgrad.back().tn = true;
+        }
     }
     // ---- eval: forward launches + a lone cost reduction that does not bump the step
     {
@@ -861,7 +866,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
 #endif
         if (L.type == 1) launch_gather(h->cfg.compute_dtype, L.ga, L.blocks, s);
         else if (L.type == 2) launch_col2im(h->cfg.compute_dtype, L.ca, L.blocks, s);
-        else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
+        else launch_grouped(h->cfg.compute_dtype, L.cfg, L.tn, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to
             std::fprintf(stderr, "[avae] launch %s type=%d cfg=%d items=%d blocks=%d\n", L.name.c_str(), L.type, L.cfg, L.count, L.blocks);
             for (int i = 0; i < L.args.n_items && L.type == 0; ++i)

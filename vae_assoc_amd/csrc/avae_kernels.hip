@@ -110,6 +110,50 @@ template <> __device__ __forceinline__ void mma<float>(const u32x4& a, const u32
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], c, 0, 0, 0);
 }
 
+// ---- K-major ("TN") operand images, used by the weight gradients: dW[m][n] = sum_k X[k][m] * dA[k][n] reads X and dA
+// as they are stored (row = batch sample k), so no transposed copy of any activation or gradient has to exist.
+// Image of one operand part: sub-images of EPR k-rows x 128 bytes (EPR = 64 bf16 / 32 fp32 columns), sub-image s
+// holding columns [s*EPR, (s+1)*EPR).  16-byte chunk c of row k lives at chunk c ^ tn_swz(k):
+//   bf16: fragments come from ds_read_b64_tr_b16 (per 16 lanes a 4-row x 16-column block, delivered column-major:
+//         lane 4q+p supplies the address of row q, columns 4p..4p+3 and receives column (lane & 15) of the 4 rows);
+//         a 32-lane half reads rows {r, r+2 | r+1, r+3} of two blocks 8 rows apart in the same columns, which the
+//         swizzle bits (row bit 1 -> chunk bit 1, row bit 3 -> chunk bit 2) spread over all 64 banks;
+//   fp32: plain ds_read_b32, lane (m, g) takes rows 4g..4g+3 of a 16-row slab; odd rows are shifted by 4 chunks.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+template <typename CT> __device__ __forceinline__ int tn_swz(int k);
+template <> __device__ __forceinline__ int tn_swz<__bf16>(int k) { return (((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2); }
+template <> __device__ __forceinline__ int tn_swz<float>(int k) { return (k & 1) << 2; }
+// byte offset, inside the operand part, of the lane's first read for the fragment whose 16 columns start at col0
+template <typename CT> __device__ __forceinline__ int tn_frag_off(int col0, int lane);
+template <> __device__ __forceinline__ int tn_frag_off<__bf16>(int col0, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int sub = col0 >> 6, mc = col0 & 63;
+    const int s = (((q >> 1) & 1) << 1) | ((g & 1) << 2);                 // tn_swz of every row this lane addresses
+    return (sub * 64 + 8 * g + q) * kTileBytesK + ((((mc >> 3) + (p >> 1)) ^ s) << 4) + 8 * (p & 1);
+}
+template <> __device__ __forceinline__ int tn_frag_off<float>(int col0, int lane) {
+    const int g = lane >> 4, mc = (col0 & 31) + (lane & 15);
+    return ((col0 >> 5) * 32 + 4 * g) * kTileBytesK + ((mc >> 2) << 4) + ((mc & 3) << 2);   // row 4g of slab 0, chunk not yet swizzled
+}
+template <typename CT> __device__ __forceinline__ u32x4 tn_frag(const unsigned char* part, int off, int slab);
+template <> __device__ __forceinline__ u32x4 tn_frag<__bf16>(const unsigned char* part, int off, int slab) {
+    const unsigned char* a = part + off + slab * (32 * kTileBytesK);       // K slab = 32 rows
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a));                       // k = 8g .. 8g+3
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + 4 * kTileBytesK));     // k = 8g+4 .. 8g+7
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(u32x4, v);
+}
+template <> __device__ __forceinline__ u32x4 tn_frag<float>(const unsigned char* part, int off, int slab) {
+    const int o = off + slab * (16 * kTileBytesK);                           // K slab = 16 rows
+    u32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)                                              // row 4g+e: odd rows sit 4 chunks (64 B) away
+        v[e] = *reinterpret_cast<const unsigned*>(part + ((o + e * kTileBytesK) ^ ((e & 1) << 6)));
+    return v;
+}
+
 // Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp): the epilogues are
 // latency-critical and libm's expf/logf/division cost tens of instructions each.
 __device__ __forceinline__ float fexp(float x) { return __expf(x); }
@@ -362,7 +406,7 @@ int tile_lds_bytes(int tile_cfg, bool two_c_tiles) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char avae_dyn_smem[];
 
-template <typename CT, int BM, int BN, int RING, int NW = 4>
+template <typename CT, int BM, int BN, int RING, int NW = 4, bool TN = false>
 __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const LaunchArgs args, DevState* st, int lds_bytes,
                                                       unsigned long long* stamps, int launch_id) {
     unsigned char* smem = avae_dyn_smem;
@@ -404,7 +448,7 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
     constexpr int NT = NW * 64;
-    if constexpr (NW == 4) {
+    if constexpr (NW == 4 && !TN) {
         if (w.kind == K_LATENT) { latent_item(w, t, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
         if (w.kind == K_COST) { cost_item(w, st, red); AVAE_STAMP(4) AVAE_STAMP_FLUSH() return; }
     }
@@ -419,9 +463,11 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     const int tm = t / w.tiles_n, tn = t - tm * w.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const unsigned char* Ag = reinterpret_cast<const unsigned char*>(w.A) + (size_t)m0 * w.lda * ES;
-    const unsigned char* Bg = reinterpret_cast<const unsigned char*>(w.B) + (size_t)n0 * w.ldb * ES;
+    // NT: the tile's rows are rows of A / B (K contiguous).  TN: its rows are K (batch samples), its columns m0.. / n0..
+    const unsigned char* Ag = reinterpret_cast<const unsigned char*>(w.A) + (TN ? (size_t)m0 * ES : (size_t)m0 * w.lda * ES);
+    const unsigned char* Bg = reinterpret_cast<const unsigned char*>(w.B) + (TN ? (size_t)n0 * ES : (size_t)n0 * w.ldb * ES);
     const size_t lda_b = (size_t)w.lda * ES, ldb_b = (size_t)w.ldb * ES;
+    constexpr int EPR = kTileBytesK / ES;          // elements per 128-byte image row = K extent of one stage
     const int nk = (w.K * ES) / kTileBytesK;
 
     f32x4 acc[MI][NI];
@@ -443,21 +489,38 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     constexpr int NCH = R8 / NW;               // per wave
     const int fr = lane & 15, fq = lane >> 4;
     const unsigned char* src[NCH];
+    size_t kadv[NCH];                                                    // bytes from one K tile to the next (TN: EPR rows)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int r = (c * NW + wave) * 8 + (lane >> 3);                // row of the (A rows, then B rows) tile image
-        const int lc = (lane & 7) ^ ((r >> 1) & 7);                     // logical chunk this lane fetches
-        src[c] = (r < BM ? Ag + (size_t)r * lda_b : Bg + (size_t)(r - BM) * ldb_b) + lc * 16;
+        const int r = (c * NW + wave) * 8 + (lane >> 3);                // row of the (A part, then B part) tile image
+        if constexpr (TN) {
+            static_assert(BM % EPR == 0 && BN % EPR == 0, "K-major images are made of EPR x EPR sub-images");
+            const bool is_a = r < BM;
+            const int rr = is_a ? r : r - BM, sub = rr / EPR, k = rr - sub * EPR;
+            const int lc = (lane & 7) ^ tn_swz<CT>(k);                  // logical chunk this lane fetches
+            const size_t ld_b = is_a ? lda_b : ldb_b;
+            src[c] = (is_a ? Ag : Bg) + (size_t)k * ld_b + (size_t)sub * kTileBytesK + lc * 16;
+            kadv[c] = (size_t)EPR * ld_b;
+        } else {
+            const int lc = (lane & 7) ^ ((r >> 1) & 7);                 // logical chunk this lane fetches
+            src[c] = (r < BM ? Ag + (size_t)r * lda_b : Bg + (size_t)(r - BM) * ldb_b) + lc * 16;
+            kadv[c] = kTileBytesK;
+        }
     }
     const int sw0 = (fq ^ (fr >> 1)) * 16;                              // swizzled chunk of K-slab 0; slab 1 = ^64
     const int aoff = (wr * WM + fr) * kTileBytesK;
     const int boff = (BM + wc * WN + fr) * kTileBytesK;
+    int offA[MI], offB[NI];                                              // TN: first-read offsets of the wave's fragments
+#pragma unroll
+    for (int i = 0; i < MI; ++i) offA[i] = TN ? tn_frag_off<CT>(wr * WM + i * 16, lane) : 0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) offB[j] = TN ? BM * kTileBytesK + tn_frag_off<CT>(wc * WN + j * 16, lane) : 0;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
 #define AVAE_DMA(kt, buf)                                                                              \
     {                                                                                                  \
         _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                                \
-            __builtin_amdgcn_global_load_lds((gp_t)(src[c] + (size_t)(kt) * kTileBytesK),              \
+            __builtin_amdgcn_global_load_lds((gp_t)(src[c] + (size_t)(kt) * (TN ? kadv[c] : (size_t)kTileBytesK)), \
                 (lp_t)(smem + (buf) * TileSmem<BM, BN, RING>::kStage + (c * NW + wave_u) * 1024), 16, 0, 0); \
     }
 #define AVAE_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -473,21 +536,25 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     // stalls on the CU's vector-memory path and the matrix pipe idles -- at the same time; waves 4-7 therefore
     // issue their refill AFTER their MFMAs: one wave of each SIMD multiplies while the other issues.
     const bool dma_late = NW == 8 && wave_u >= 4;
+    /* fragment f of K-slab `slab`: NT = one ds_read_b128 of the row image, TN = transposed reads of the K-major image */
+#define AVAE_FRAG(nt_off, tn_offs, f, slab)                                                            \
+    (TN ? tn_frag<CT>(Sb, (tn_offs)[f], slab)                                                          \
+        : *reinterpret_cast<const u32x4*>(Sb + (nt_off) + (f) * 16 * kTileBytesK + ((slab) ? (sw0 ^ 64) : sw0)))
 #define AVAE_COMPUTE(buf, do_dma, dma_kt, dma_buf)                                                     \
     {                                                                                                  \
         const unsigned char* Sb = smem + (buf) * TileSmem<BM, BN, RING>::kStage;                       \
         u32x4 a0[MI], b0[NI], a1[MI], b1[NI];      /* both K slabs' fragments: the second slab's LDS  */ \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)   /* latency hides behind the first slab's MFMAs */ \
-            a0[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + sw0);           \
+            a0[i] = AVAE_FRAG(aoff, offA, i, 0);                                                       \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
-            b0[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + sw0);           \
+            b0[j] = AVAE_FRAG(boff, offB, j, 0);                                                       \
         AVAE_LGKM0(); AVAE_LT(2)                                                                       \
         if ((do_dma) && !dma_late) AVAE_ABL_DMA(dma_kt, dma_buf)                                       \
         AVAE_LT(3)                                                                                     \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
-            a1[i] = *reinterpret_cast<const u32x4*>(Sb + aoff + i * 16 * kTileBytesK + (sw0 ^ 64));    \
+            a1[i] = AVAE_FRAG(aoff, offA, i, 1);                                                       \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
-            b1[j] = *reinterpret_cast<const u32x4*>(Sb + boff + j * 16 * kTileBytesK + (sw0 ^ 64));    \
+            b1[j] = AVAE_FRAG(boff, offB, j, 1);                                                       \
         AVAE_LGKM0(); AVAE_LT(4)                                                                       \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
             _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a0[i], b0[j], acc[i][j]);           \
@@ -542,6 +609,7 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
 #undef AVAE_DMA
 #undef AVAE_WAIT
 #undef AVAE_COMPUTE
+#undef AVAE_FRAG
 
     // ---- epilogue: accumulators -> LDS tile (fp32), then kind-specific fused passes
     float* Cs = reinterpret_cast<float*>(smem);
@@ -560,6 +628,10 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
 
     const int M = w.M, N = w.N;
     constexpr int QC = BN / 4;
+    if constexpr (TN) {      // the weight gradients are the only K-major products
+        tile_pass<float, float, false, false, BM, BN, NT>(Cs, reinterpret_cast<float*>(w.out0), w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
+            [](float c, float, bool) { return c; });
+    } else
     switch (w.kind) {
     case K_FWD_HIDDEN: {
         CT* Y = reinterpret_cast<CT*>(w.out0);
@@ -752,24 +824,26 @@ template <typename K> static void set_max_lds(K kernel) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
+void launch_grouped(int compute_dtype, int tile_cfg, bool tn, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
                     DevState* st, hipStream_t s, unsigned long long* stamps, int launch_id) {
     static const bool once = [] {
         set_max_lds(k_grouped<__bf16, 64, 64, 4>); set_max_lds(k_grouped<__bf16, 128, 128, 2>); set_max_lds(k_grouped<__bf16, 256, 128, 3, 8>);
         set_max_lds(k_grouped<float, 64, 64, 4>); set_max_lds(k_grouped<float, 128, 128, 2>); set_max_lds(k_grouped<float, 256, 128, 3, 8>);
+        set_max_lds(k_grouped<__bf16, 64, 64, 4, 4, true>); set_max_lds(k_grouped<__bf16, 128, 128, 2, 4, true>); set_max_lds(k_grouped<__bf16, 256, 128, 3, 8, true>);
+        set_max_lds(k_grouped<float, 64, 64, 4, 4, true>); set_max_lds(k_grouped<float, 128, 128, 2, 4, true>); set_max_lds(k_grouped<float, 256, 128, 3, 8, true>);
         return true;
     }();
     (void)once;
     dim3 grid(grid_x, grid_y), block(tile_cfg == 2 ? 512 : kThreads);
-    if (compute_dtype == AVAE_BF16) {
-        if (tile_cfg == 0) AVAE_LAUNCH((k_grouped<__bf16, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-        else if (tile_cfg == 2) AVAE_LAUNCH((k_grouped<__bf16, 256, 128, 3, 8>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-        else AVAE_LAUNCH((k_grouped<__bf16, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-    } else {
-        if (tile_cfg == 0) AVAE_LAUNCH((k_grouped<float, 64, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-        else if (tile_cfg == 2) AVAE_LAUNCH((k_grouped<float, 256, 128, 3, 8>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-        else AVAE_LAUNCH((k_grouped<float, 128, 128, 2>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-    }
+#define AVAE_GO(CT, TNF)                                                                                                     \
+    do {                                                                                                                     \
+        if (tile_cfg == 0) AVAE_LAUNCH((k_grouped<CT, 64, 64, 4, 4, TNF>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);        \
+        else if (tile_cfg == 2) AVAE_LAUNCH((k_grouped<CT, 256, 128, 3, 8, TNF>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id); \
+        else AVAE_LAUNCH((k_grouped<CT, 128, 128, 2, 4, TNF>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);                    \
+    } while (0)
+    if (compute_dtype == AVAE_BF16) { if (tn) AVAE_GO(__bf16, true); else AVAE_GO(__bf16, false); }
+    else { if (tn) AVAE_GO(float, true); else AVAE_GO(float, false); }
+#undef AVAE_GO
 }
 
 // ------------------------------------------------------------------ Adam + shadow refresh
