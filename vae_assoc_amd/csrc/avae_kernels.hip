@@ -138,13 +138,21 @@ template <> __device__ __forceinline__ int tn_frag_off<float>(int col0, int lane
 }
 template <typename CT> __device__ __forceinline__ u32x4 tn_frag(const unsigned char* part, int off, int slab);
 template <> __device__ __forceinline__ u32x4 tn_frag<__bf16>(const unsigned char* part, int off, int slab) {
-    const unsigned char* a = part + off + slab * (32 * kTileBytesK);       // K slab = 32 rows
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a));                       // k = 8g .. 8g+3
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + 4 * kTileBytesK));     // k = 8g+4 .. 8g+7
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(u32x4, v);
+    // Inline asm on purpose: through the builtin the compiler guards every transposed read with s_waitcnt vmcnt(0)
+    // (it treats it as possibly aliasing the LDS-DMA refills in flight), which serialises the ring.  The price is that
+    // the results are only valid after tn_frags_ready() below.
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)(part + off + slab * (32 * kTileBytesK));   // K slab = 32 rows
+    unsigned long long lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));                 // k = 8g .. 8g+3
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(hi) : "v"(a));      // k = 8g+4 .. 8g+7 (4 rows of 128 B further)
+    return u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
 }
+// all transposed reads issued so far have landed; `f` are the fragments whose consumers must come after the wait
+template <int N> __device__ __forceinline__ void tn_frags_ready(u32x4 (&f)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i]));
+}
+__device__ __forceinline__ void tn_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <> __device__ __forceinline__ u32x4 tn_frag<float>(const unsigned char* part, int off, int slab) {
     const int o = off + slab * (16 * kTileBytesK);                           // K slab = 16 rows
     u32x4 v;
@@ -555,6 +563,7 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
             a1[i] = AVAE_FRAG(aoff, offA, i, 1);                                                       \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
             b1[j] = AVAE_FRAG(boff, offB, j, 1);                                                       \
+        if constexpr (TN && sizeof(CT) == 2) { tn_wait_lds(); tn_frags_ready(a0); tn_frags_ready(b0); tn_frags_ready(a1); tn_frags_ready(b1); } \
         AVAE_LGKM0(); AVAE_LT(4)                                                                       \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
             _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a0[i], b0[j], acc[i][j]);           \
