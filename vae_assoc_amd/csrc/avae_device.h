@@ -116,7 +116,6 @@ struct PrepSeg {
     int rows, cols;
     float* dst32; int ld32;        // nullable
     void* dstc; int ldc;           // row-major compute dtype
-    void* dstct; int ldct;         // transposed compute dtype, nullable
     int tiles_r, tiles_c, tile_base;
 };
 struct PrepArgs {
@@ -153,7 +152,6 @@ struct GatherSeg {
     ConvGeom g;
     const void* src;
     void* P; int ldp;
-    void* Pt; int ldpt;        // nullable
     int tiles_r, tiles_c, tile_base;
 };
 struct GatherArgs { GatherSeg seg[kMaxMod]; int n_seg; };
@@ -165,7 +163,6 @@ struct Col2imSeg {
     const void* yprev; int ldy;      // stored output of the producing layer (nullable -> identity)
     int act;                          // AVAE_ACT_* of the producing layer
     void* dA; int lda;                // [B*IH*IW][lda]
-    void* dAt; int ldat;              // [Cin (or 2*nz)][ldat]
     const float* g0; int nz;          // latent mode when g0 != nullptr
     int tiles_r, tiles_c, tile_base;
 };

@@ -51,11 +51,11 @@ struct Dense {             // one dense layer, weights + bias as W_aug [(in+1)][
     bool head = false;     // [mu|sigma] fused head: flat layout is Wmu,bmu,Wsig,bsig
 };
 
-struct Act {               // activation or gradient: row-major [rows p][ld] + transposed [rup(width+1,128)][ldT]
+struct Act {               // activation or gradient: row-major [rows p][ld] (every consumer reads it as stored)
     int width = 0;
     int rows = 0;          // logical rows (batch, or batch * output pixels for a conv stage)
-    int ld = 0, ldT = 0;
-    size_t rm = 0, tr = 0;
+    int ld = 0;
+    size_t rm = 0;
     bool ones = false;
 };
 
@@ -147,15 +147,13 @@ struct avae_handle {
 
 namespace {
 
-Act make_act(Bump& b, int width, bool ones, int rows, int KU, int es, bool want_rm = true, bool want_tr = true) {
+Act make_act(Bump& b, int width, bool ones, int rows, int KU, int es) {
     Act a;
     a.width = width;
     a.rows = rows;
     a.ones = ones;
     a.ld = (int)rup(width + 1, KU);
-    a.ldT = (int)rup(rows, KU);
-    if (want_rm) a.rm = b.take(rup(rows, kRowAlign) * (size_t)a.ld * es);
-    if (want_tr) a.tr = b.take(rup(width + 1, kRowAlign) * (size_t)a.ldT * es);
+    a.rm = b.take(rup(rows, kRowAlign) * (size_t)a.ld * es);
     return a;
 }
 
@@ -263,7 +261,7 @@ void plan_memory(avae_handle* h) {
                 st.d = make_dense(b, pint, K, Cout, KU, es, flat == 3);
                 st.P = make_act(b, K, bias, rows, KU, es);
                 if (plain_out) {     // hidden conv stage: own output / gradient buffers
-                    st.Y = make_act(b, Cout, false, rows, KU, es, true, false);
+                    st.Y = make_act(b, Cout, false, rows, KU, es);
                     st.dY = make_act(b, Cout, false, rows, KU, es);
                 }
                 st.lddp = (int)rup(K, 8);
@@ -385,7 +383,7 @@ struct Builder {
     avae_handle* h;
     std::vector<WorkItem>& items;
     int B;      // rows of this plan (batch or inference rows)
-    bool train; // write transposed copies
+    bool train; // training plan (losses, gradients) or inference plan
     int next_slot = 0;
     Builder(avae_handle* h_, std::vector<WorkItem>& it, int rows, bool tr) : h(h_), items(it), B(rows), train(tr) {}
     template <typename T> T* p(size_t off) const { return h->at<T>(off); }
@@ -395,7 +393,6 @@ struct Builder {
         WorkItem w = gemm_item(K_FWD_HIDDEN, B, d.out, K_of(d.in + 1), p<void>(in.rm), in.ld, p<void>(d.Wt), d.ldt);
         w.act = h->cfg.activation;
         w.out0 = p<void>(out.rm); w.ld0 = out.ld;
-        w.out1 = train ? p<void>(out.tr) : nullptr; w.ld1 = out.ldT;
         return w;
     }
     WorkItem fwd_head(const Mod& md, bool with_z) {
@@ -404,7 +401,6 @@ struct Builder {
         w.nz = h->nz;
         w.out0 = p<void>(md.mulv); w.ld0 = 2 * h->nz;
         w.out1 = with_z ? p<void>(md.Z.rm) : nullptr; w.ld1 = md.Z.ld;
-        w.out2 = (with_z && train) ? p<void>(md.Z.tr) : nullptr; w.ld2 = md.Z.ldT;
         w.aux0 = p<void>(h->off_eps); w.ldx = h->ld_eps;
         return w;
     }
@@ -418,7 +414,6 @@ struct Builder {
             w.scale = w.binary ? h->cfg.mod[m].weight / bg : h->cfg.mod[m].weight;
             w.aux0 = p<void>(md.X32); w.ldx = md.ld32;
             w.out0 = p<void>(md.dO.rm); w.ld0 = md.dO.ld;
-            w.out1 = p<void>(md.dO.tr); w.ld1 = md.dO.ldT;
             w.partial = p<float>(h->off_partial);
         } else {
             w.out0 = p<void>(md.out32); w.ld0 = md.ld32;
@@ -430,7 +425,6 @@ struct Builder {
         w.act = h->cfg.activation;
         w.aux0 = p<void>(yprev.rm); w.ldx = yprev.ld;
         w.out0 = p<void>(dprev.rm); w.ld0 = dprev.ld;
-        w.out1 = p<void>(dprev.tr); w.ld1 = dprev.ldT;
         return w;
     }
     WorkItem dgrad_latent(const Mod& md) {
@@ -440,7 +434,6 @@ struct Builder {
         w.nz = h->nz;
         w.aux2 = p<void>(md.g0);
         w.out0 = p<void>(md.dH.rm); w.ld0 = md.dH.ld;
-        w.out1 = p<void>(md.dH.tr); w.ld1 = md.dH.ldT;
         return w;
     }
     // ---- conv branch: every stage is a GEMM on its patch matrix
@@ -456,13 +449,12 @@ struct Builder {
         w.out0 = p<void>(st.dP); w.ld0 = st.lddp;
         return w;
     }
-    GatherSeg gather_seg(const ConvStage& st, const void* src, bool with_t) {
+    GatherSeg gather_seg(const ConvStage& st, const void* src) {
         GatherSeg g;
         std::memset(&g, 0, sizeof(g));
         g.g = st.g; g.g.B = B;
         g.src = src;
         g.P = p<void>(st.P.rm); g.ldp = st.P.ld;
-        g.Pt = with_t ? p<void>(st.P.tr) : nullptr; g.ldpt = st.P.ldT;
         const int M = conv_rows(st), KC = st.d.in + (st.bias ? 1 : 0);
         g.tiles_r = (M + 63) / 64; g.tiles_c = (KC + 63) / 64;
         return g;
@@ -477,12 +469,10 @@ struct Builder {
         if (prev) {
             c.yprev = prev->act == AVAE_ACT_IDENTITY ? nullptr : p<void>(prev->Y.rm); c.ldy = prev->Y.ld; c.act = prev->act;
             c.dA = p<void>(prev->dY.rm); c.lda = prev->dY.ld;
-            c.dAt = p<void>(prev->dY.tr); c.ldat = prev->dY.ldT;
             C = st.g.Cin;
         } else {
             c.g0 = p<float>(md.g0); c.nz = h->nz;
             c.dA = p<void>(md.dH.rm); c.lda = md.dH.ld;
-            c.dAt = p<void>(md.dH.tr); c.ldat = md.dH.ldT;
             C = 2 * h->nz;
         }
         const int R = B * st.g.IH * st.g.IW;
@@ -605,7 +595,7 @@ void build_training_plan(avae_handle* h) {
         L.name = name; L.type = 1;
         int base = 0;
         for (Mod& md : h->mods) if (md.conv) {
-            GatherSeg g = bd.gather_seg(stage_of(md), src_of(md), true);
+            GatherSeg g = bd.gather_seg(stage_of(md), src_of(md));
             g.tile_base = base; base += g.tiles_r * g.tiles_c;
             L.ga.seg[L.ga.n_seg++] = g;
         }
@@ -801,7 +791,7 @@ void build_inference(avae_handle* h, int m, bool enc, int rows) {
     auto gather1 = [&](const ConvStage& st, const void* src, const std::string& name) {
         Launch L;
         L.name = name; L.type = 1;
-        GatherSeg g = bd.gather_seg(st, src, false);      // inference never touches the transposed (K = batch) copies
+        GatherSeg g = bd.gather_seg(st, src);
         g.tile_base = 0;
         L.ga.seg[0] = g; L.ga.n_seg = 1;
         L.blocks = g.tiles_r * g.tiles_c;
@@ -873,12 +863,12 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
                 std::fprintf(stderr, "        item kind=%d M=%d N=%d K=%d lda=%d ldb=%d tiles=%dx%d base=%d\n", L.args.items[i].kind, L.args.items[i].M,
                              L.args.items[i].N, L.args.items[i].K, L.args.items[i].lda, L.args.items[i].ldb, L.args.items[i].tiles_m, L.args.items[i].tiles_n, L.args.items[i].tile_base);
             for (int i = 0; i < L.ga.n_seg && L.type == 1; ++i)
-                std::fprintf(stderr, "        gather B=%d IH=%d Cin=%d OH=%d k=%d so=%d d=%d pad=%d sb=%d sp=%d ones=%d ldp=%d ldpt=%d Pt=%p tiles=%dx%d\n", L.ga.seg[i].g.B, L.ga.seg[i].g.IH,
+                std::fprintf(stderr, "        gather B=%d IH=%d Cin=%d OH=%d k=%d so=%d d=%d pad=%d sb=%d sp=%d ones=%d ldp=%d tiles=%dx%d\n", L.ga.seg[i].g.B, L.ga.seg[i].g.IH,
                              L.ga.seg[i].g.Cin, L.ga.seg[i].g.OH, L.ga.seg[i].g.k, L.ga.seg[i].g.so, L.ga.seg[i].g.d, L.ga.seg[i].g.pad, L.ga.seg[i].g.src_sb, L.ga.seg[i].g.src_sp,
-                             L.ga.seg[i].g.ones, L.ga.seg[i].ldp, L.ga.seg[i].ldpt, L.ga.seg[i].Pt, L.ga.seg[i].tiles_r, L.ga.seg[i].tiles_c);
+                             L.ga.seg[i].g.ones, L.ga.seg[i].ldp, L.ga.seg[i].tiles_r, L.ga.seg[i].tiles_c);
             for (int i = 0; i < L.ca.n_seg && L.type == 2; ++i)
-                std::fprintf(stderr, "        col2im B=%d IH=%d Cin=%d OH=%d k=%d lddp=%d lda=%d ldat=%d dAt=%p g0=%p tiles=%dx%d\n", L.ca.seg[i].g.B, L.ca.seg[i].g.IH, L.ca.seg[i].g.Cin,
-                             L.ca.seg[i].g.OH, L.ca.seg[i].g.k, L.ca.seg[i].lddp, L.ca.seg[i].lda, L.ca.seg[i].ldat, L.ca.seg[i].dAt, (const void*)L.ca.seg[i].g0, L.ca.seg[i].tiles_r, L.ca.seg[i].tiles_c);
+                std::fprintf(stderr, "        col2im B=%d IH=%d Cin=%d OH=%d k=%d lddp=%d lda=%d g0=%p tiles=%dx%d\n", L.ca.seg[i].g.B, L.ca.seg[i].g.IH, L.ca.seg[i].g.Cin,
+                             L.ca.seg[i].g.OH, L.ca.seg[i].g.k, L.ca.seg[i].lddp, L.ca.seg[i].lda, (const void*)L.ca.seg[i].g0, L.ca.seg[i].tiles_r, L.ca.seg[i].tiles_c);
             std::fflush(stderr);
             HIP_OK(hipStreamSynchronize(s));
         }
@@ -913,7 +903,6 @@ PrepArgs make_prep_batch(avae_handle* h, const float* const* x, const int32_t* x
         g.rows = rows; g.cols = md.n_in;
         g.dst32 = h->at<float>(md.X32); g.ld32 = md.ld32;
         g.dstc = h->at<void>(md.X0.rm); g.ldc = md.X0.ld;
-        g.dstct = h->at<void>(md.X0.tr); g.ldct = md.X0.ldT;
         g.tiles_r = (rows + 63) / 64; g.tiles_c = (md.n_in + 63) / 64; g.tile_base = base;
         base += g.tiles_r * g.tiles_c;
     }
@@ -941,7 +930,6 @@ void run_prep_single(avae_handle* h, const float* src, int src_ld, int rows, int
         g.src = src; g.src_ld = src_ld; g.rows = rows; g.cols = cols;
         g.dst32 = dst32; g.ld32 = ld32;
         g.dstc = h->at<void>(dst.rm); g.ldc = dst.ld;
-        g.dstct = nullptr;               // inference never touches the transposed (K = batch) copies
         g.tiles_r = (rows + 63) / 64; g.tiles_c = (cols + 63) / 64; g.tile_base = 0;
         a.n_seg = 1; a.total_tiles = g.tiles_r * g.tiles_c;
     }
@@ -1024,7 +1012,6 @@ void fill_ones(avae_handle* h, const Act& a, hipStream_t s) {
     if (!a.ones) return;
     const unsigned bits = h->es == 2 ? 0x3F80u : 0x3F800000u;
     launch_fill(h->at<void>(a.rm), h->es, bits, a.width, a.ld, h->B, s);             // column `width`, rows < B
-    launch_fill(h->at<void>(a.tr), h->es, bits, (long long)a.width * a.ldT, 1, h->B, s);   // row `width`, cols < B
 }
 
 void init_device(avae_handle* h) {
@@ -1033,7 +1020,7 @@ void init_device(avae_handle* h) {
     for (const Mod& md : h->mods) {
         for (int j = 0; j < kMultiSteps; ++j) {       // every staging set carries its own constant-1 column
             Act x = md.X0;
-            x.rm += (size_t)j * h->stage_bytes; x.tr += (size_t)j * h->stage_bytes;
+            x.rm += (size_t)j * h->stage_bytes;
             fill_ones(h, x, s);
         }
         for (const Act& a : md.E) fill_ones(h, a, s);

@@ -285,29 +285,6 @@ __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT*
     }
 }
 
-template <typename OT, int BM, int BN, int NT = kThreads>
-__device__ __forceinline__ void transposed_store(const float* Cs, OT* out, int ld, int M, int N, int m0, int n0) {
-    constexpr int VW = Vec16<OT>::VW;
-    constexpr int LDC = BN + 4, QR = BM / VW, NQT = BN * QR / NT;
-    constexpr int NQ = NQT < 32 / VW ? NQT : 32 / VW;
-    static_assert(NQT % NQ == 0, "tile / thread mapping");
-    for (int q0 = 0; q0 < NQT; q0 += NQ) {
-        float v[NQ][VW];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int idx = threadIdx.x + (q0 + q) * NT, col = idx / QR, r0 = (idx - col * QR) * VW;
-#pragma unroll
-            for (int e = 0; e < VW; ++e) v[q][e] = Cs[cs_idx<LDC>(r0 + e, col)];
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int idx = threadIdx.x + (q0 + q) * NT, col = idx / QR, r0 = (idx - col * QR) * VW;
-            const int gcol = n0 + col, grow = m0 + r0;
-            if (gcol < N && grow < M) store_vec<OT, VW>(out + (size_t)gcol * ld + grow, v[q], M - grow);
-        }
-    }
-}
-
 // ------------------------------------------------------------------ non-GEMM work items
 // KL(q||N(0,I)) (vae_assoc.py:335-337) and the symmetric-KL association penalty (:346-366) with
 // their gradients w.r.t. (mu, lv).  The log-determinant terms of the two directed KLs cancel, so
@@ -647,10 +624,6 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
         AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, false, true, BM, BN, NT>(Cs, Y, w.ld0, (const CT*)nullptr, 4, M, N, m0, n0,
             [](float c, float, bool) { return act_fwd_t<ACT>(c); })))
         AVAE_STAMP(6)
-        if (w.out1) {
-            lds_barrier();
-            transposed_store<CT, BM, BN, NT>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
-        }
     } break;
     case K_FWD_HEAD: {
       if constexpr (NW == 4) {     // 8-wave tiles carry the plain kinds only (host: finish_launch)
@@ -692,7 +665,6 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
             lds_barrier();
             tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out1), w.ld1, (const CT*)nullptr, 8,
                                                     M, nz, m0, 0, [](float c, float, bool) { return c; });
-            if (w.out2) transposed_store<CT, BM, BN>(Zs, reinterpret_cast<CT*>(w.out2), w.ld2, M, nz, m0, 0);
         }
       }
     } break;
@@ -724,10 +696,6 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
         }
         const float total = block_sum(csum, red);
         if (tid == 0) w.partial[w.slot_base + t] = total;
-        if (w.out1) {
-            lds_barrier();
-            transposed_store<CT, BM, BN>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
-        }
       }
     } break;
     case K_FWD_OUT_STORE: {
@@ -746,10 +714,6 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
         const CT* Yp = reinterpret_cast<const CT*>(w.aux0);
         AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, true, true, BM, BN, NT>(Cs, dX, w.ld0, Yp, w.ldx, M, N, m0, n0,
             [](float c, float y, bool) { return c * act_bwd_t<ACT>(y); })))
-        if (w.out1) {
-            lds_barrier();
-            transposed_store<CT, BM, BN, NT>(Cs, reinterpret_cast<CT*>(w.out1), w.ld1, M, N, m0, n0);
-        }
     } break;
     case K_DGRAD_LATENT: {
       if constexpr (NW == 4) {     // 8-wave tiles carry the plain kinds only (host: finish_launch)
@@ -798,7 +762,6 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
         lds_barrier();
         tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out0), w.ld0, (const CT*)nullptr, 8,
                                                 M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
-        if (w.out1) transposed_store<CT, BM, BN>(Zs, reinterpret_cast<CT*>(w.out1), w.ld1, M, 2 * nz, m0, 0);
       }
     } break;
     case K_DGRAD_F32:
@@ -950,7 +913,6 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 
 template <typename CT>
 __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
-    __shared__ float T[64][65];
     const int tid = threadIdx.x;
     const int bstep = a.n_steps > 1 ? (int)blockIdx.x / a.blocks_per_step : 0;     // which of the batched steps
     const int bid = (int)blockIdx.x - bstep * a.blocks_per_step;
@@ -1010,22 +972,6 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
             if (dst32) store_row<float>(dst32 + (size_t)grow * w.ld32 + gcol, v, nv);
             store_row<CT>(dstc + (size_t)grow * w.ldc + gcol, v, nv);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) T[r][c4 + e] = v[e];
-    }
-    if (!w.dstct) return;
-    lds_barrier();
-    const int r4 = (tid & 15) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (tid >> 4) + 16 * i;
-        const int gcol = c0 + c, grow = r0 + r4;
-        if (gcol < w.cols && grow < w.rows) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = T[r4 + e][c];
-            store_row<CT>(reinterpret_cast<CT*>(reinterpret_cast<unsigned char*>(w.dstct) + set_off) + (size_t)gcol * w.ldct + grow, v, w.rows - grow);
-        }
     }
 }
 
@@ -1048,7 +994,6 @@ template <> __device__ __forceinline__ float ct_load<__bf16>(const __bf16* p) { 
 // Patch matrix of one conv-like layer, 64 x 64 tiles (rows = output pixels, cols = (kh,kw,ci) [+ ones]).
 template <typename CT>
 __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
-    __shared__ float T[64][65];
     const int bid = blockIdx.x, tid = threadIdx.x;
     int it = 0;
     for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].tile_base) it = i;
@@ -1084,22 +1029,6 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
             }
             store_row<CT>(reinterpret_cast<CT*>(w.P) + (size_t)m * w.ldp + kc, v, KC - kc);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) T[r][c4 + e] = v[e];
-    }
-    if (!w.Pt) return;
-    lds_barrier();
-    const int r4 = (tid & 15) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (tid >> 4) + 16 * i;
-        const int kc = c0 + c, m = r0 + r4;
-        if (kc < KC && m < M) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = T[r4 + e][c];
-            store_row<CT>(reinterpret_cast<CT*>(w.Pt) + (size_t)kc * w.ldpt + m, v, M - m);
-        }
     }
 }
 
@@ -1107,7 +1036,6 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
 // patch entries that were gathered from it (no atomics), then the producing layer's act' is applied.
 template <typename CT>
 __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
-    __shared__ float T[64][65];
     const int bid = blockIdx.x, tid = threadIdx.x;
     int it = 0;
     for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].tile_base) it = i;
@@ -1156,22 +1084,6 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
                 v[e] = acc;
             }
             store_row<CT>(reinterpret_cast<CT*>(w.dA) + (size_t)pix * w.lda + cc, v, C - cc);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) T[r][c4 + e] = v[e];
-    }
-    if (!w.dAt) return;
-    lds_barrier();
-    const int r4 = (tid & 15) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (tid >> 4) + 16 * i;
-        const int cc = c0 + c, pix = r0 + r4;
-        if (cc < C && pix < R) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = T[r4 + e][c];
-            store_row<CT>(reinterpret_cast<CT*>(w.dAt) + (size_t)cc * w.ldat + pix, v, R - pix);
         }
     }
 }
