@@ -301,9 +301,9 @@ void plan_memory(avae_handle* h) {
     h->off_m = b.take(pint * 4);
     h->off_v = b.take(pint * 4);
     h->off_g = b.take((pint + 64) * 4);      // + cost slot (element P_int), padded
-    // cost partial slots: one per output-loss tile (64-wide tiles bound the count) + latent tiles
+    // cost partial slots: one per output-loss tile (the smallest tile, 32x64, bounds the count) + latent tiles
     int slots = (B + kLatentRows - 1) / kLatentRows;
-    for (int m = 0; m < h->M; ++m) slots += ((B + 63) / 64) * ((h->mods[m].n_in + 63) / 64);
+    for (int m = 0; m < h->M; ++m) slots += ((B + 31) / 32) * ((h->mods[m].n_in + 63) / 64);
     h->n_partial = slots;
     h->off_partial = b.take((size_t)slots * 4);
     h->off_state = b.take(sizeof(DevState));
@@ -540,7 +540,17 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         }
         if (L.cfg == 1 && plain && tiles256 >= 192) L.cfg = 2;
     }
-    const int T = L.cfg ? 128 : 64, TM = L.cfg == 2 ? 256 : T;
+    if (L.cfg == 0 && !std::getenv("AVAE_NO_32")) {      // few 64x64 tiles: half-height tiles put twice the CUs on the launch
+        long t64 = 0;
+        bool nt = true;
+        for (int i = first; i < first + count; ++i) {
+            const WorkItem& w = items[i];
+            if (is_gemm(w.kind)) t64 += (long)((w.M + 63) / 64) * ((w.N + 63) / 64);
+            nt = nt && w.kind != K_WGRAD && w.kind != K_DGRAD_F32;
+        }
+        if (nt && t64 > 0 && t64 <= 128) L.cfg = 3;
+    }
+    const int T = (L.cfg == 1 || L.cfg == 2) ? 128 : 64, TM = L.cfg == 2 ? 256 : L.cfg == 3 ? 32 : T;
     int max_tiles = 1;
     for (int i = first; i < first + count; ++i) {
         WorkItem& w = items[i];
