@@ -35,9 +35,8 @@ struct WorkItem {
     int M, N, K;             // K is the padded extent (multiple of the K unit)
     int lda, ldb;            // in elements of the compute type
     int tiles_m, tiles_n;
-    int tile_base;           // first block of this item inside its launch
     int act;                 // AVAE_ACT_*
-    int ld0, ld1, ld2, ldx;
+    int ld0, ld1, ldx;
     int nz;
     int binary;
     int slot_base;           // first cost-partial slot written by this item

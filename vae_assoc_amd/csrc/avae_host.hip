@@ -550,11 +550,20 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         }
         if (nt && t64 > 0 && t64 <= 128) L.cfg = 3;
     }
-    const int T = (L.cfg == 1 || L.cfg == 2) ? 128 : 64, TM = L.cfg == 2 ? 256 : L.cfg == 3 ? 32 : T;
+    if (L.cfg == 1 && need128 && !std::getenv("AVAE_NO_64x128")) {      // wide-latent head launches: few tiles, K loop = load latency
+        long t = 0;
+        bool nt = true;
+        for (int i = first; i < first + count; ++i) {
+            const WorkItem& w = items[i];
+            if (is_gemm(w.kind)) t += (long)((w.M + 63) / 64) * ((w.N + 127) / 128);
+            nt = nt && w.kind != K_WGRAD && w.kind != K_DGRAD_F32;
+        }
+        if (nt && t <= 256) L.cfg = 4;
+    }
+    const int T = (L.cfg == 1 || L.cfg == 2 || L.cfg == 4) ? 128 : 64, TM = L.cfg == 2 ? 256 : L.cfg == 3 ? 32 : L.cfg == 4 ? 64 : T;
     int max_tiles = 1;
     for (int i = first; i < first + count; ++i) {
         WorkItem& w = items[i];
-        w.tile_base = 0;
         if (is_gemm(w.kind)) {
             w.tiles_m = (w.M + TM - 1) / TM;
             w.tiles_n = (w.N + T - 1) / T;
@@ -870,8 +879,8 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to
             std::fprintf(stderr, "[avae] launch %s type=%d cfg=%d items=%d blocks=%d\n", L.name.c_str(), L.type, L.cfg, L.count, L.blocks);
             for (int i = 0; i < L.args.n_items && L.type == 0; ++i)
-                std::fprintf(stderr, "        item kind=%d M=%d N=%d K=%d lda=%d ldb=%d tiles=%dx%d base=%d\n", L.args.items[i].kind, L.args.items[i].M,
-                             L.args.items[i].N, L.args.items[i].K, L.args.items[i].lda, L.args.items[i].ldb, L.args.items[i].tiles_m, L.args.items[i].tiles_n, L.args.items[i].tile_base);
+                std::fprintf(stderr, "        item kind=%d M=%d N=%d K=%d lda=%d ldb=%d tiles=%dx%d\n", L.args.items[i].kind, L.args.items[i].M,
+                             L.args.items[i].N, L.args.items[i].K, L.args.items[i].lda, L.args.items[i].ldb, L.args.items[i].tiles_m, L.args.items[i].tiles_n);
             for (int i = 0; i < L.ga.n_seg && L.type == 1; ++i)
                 std::fprintf(stderr, "        gather B=%d IH=%d Cin=%d OH=%d k=%d so=%d d=%d pad=%d sb=%d sp=%d ones=%d ldp=%d tiles=%dx%d\n", L.ga.seg[i].g.B, L.ga.seg[i].g.IH,
                              L.ga.seg[i].g.Cin, L.ga.seg[i].g.OH, L.ga.seg[i].g.k, L.ga.seg[i].g.so, L.ga.seg[i].g.d, L.ga.seg[i].g.pad, L.ga.seg[i].g.src_sb, L.ga.seg[i].g.src_sp,

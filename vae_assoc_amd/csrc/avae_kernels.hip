@@ -384,7 +384,13 @@ template <int BM, int BN, int RING> struct TileSmem {
 // tile_cfg: 0 = 64x64 tile, 4-stage ring; 1 = 128x128 tile, 2-stage ring, two workgroups per CU;
 //           2 = 256x128 tile, 3-stage ring, one workgroup per CU (big single-C-tile kinds only)
 //           3 = 32x64 tile, 4-stage ring (NT launches with too few 64x64 tiles to occupy the chip)
+//           4 = 64x128 tile, 4-stage ring (wide-latent head / latent-dgrad launches with few tiles: three K tiles in
+//               flight instead of one, twice the workgroups of cfg 1)
 int tile_lds_bytes(int tile_cfg, bool two_c_tiles) {
+    if (tile_cfg == 4) {
+        const int st = TileSmem<64, 128, 4>::kStages, c4 = TileSmem<64, 128, 4>::kC * (two_c_tiles ? 2 : 1);
+        return (st > c4 ? st : c4) + 64;
+    }
     const int stages = tile_cfg == 3 ? TileSmem<32, 64, 4>::kStages : tile_cfg == 2 ? TileSmem<256, 128, 3>::kStages : tile_cfg == 1 ? TileSmem<128, 128, 2>::kStages : TileSmem<64, 64, 4>::kStages;
     const int c = (tile_cfg == 3 ? TileSmem<32, 64, 4>::kC : tile_cfg == 2 ? TileSmem<256, 128, 3>::kC : tile_cfg == 1 ? TileSmem<128, 128, 2>::kC : TileSmem<64, 64, 4>::kC) * (two_c_tiles ? 2 : 1);
     return (stages > c ? stages : c) + 64;                     // + block-reduction scratch
@@ -803,6 +809,7 @@ void launch_grouped(int compute_dtype, int tile_cfg, bool tn, const LaunchArgs& 
         set_max_lds(k_grouped<__bf16, 64, 64, 4>); set_max_lds(k_grouped<__bf16, 128, 128, 2>); set_max_lds(k_grouped<__bf16, 256, 128, 3, 8>);
         set_max_lds(k_grouped<float, 64, 64, 4>); set_max_lds(k_grouped<float, 128, 128, 2>); set_max_lds(k_grouped<float, 256, 128, 3, 8>);
         set_max_lds(k_grouped<__bf16, 32, 64, 4>); set_max_lds(k_grouped<float, 32, 64, 4>);
+        set_max_lds(k_grouped<__bf16, 64, 128, 4>); set_max_lds(k_grouped<float, 64, 128, 4>);
         set_max_lds(k_grouped<__bf16, 64, 64, 4, 4, true>); set_max_lds(k_grouped<__bf16, 128, 128, 2, 4, true>); set_max_lds(k_grouped<__bf16, 256, 128, 3, 8, true>);
         set_max_lds(k_grouped<float, 64, 64, 4, 4, true>); set_max_lds(k_grouped<float, 128, 128, 2, 4, true>); set_max_lds(k_grouped<float, 256, 128, 3, 8, true>);
         return true;
@@ -818,6 +825,9 @@ void launch_grouped(int compute_dtype, int tile_cfg, bool tn, const LaunchArgs& 
     if (tile_cfg == 3) {      // NT only
         if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_grouped<__bf16, 32, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
         else AVAE_LAUNCH((k_grouped<float, 32, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+    } else if (tile_cfg == 4) {      // NT only
+        if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_grouped<__bf16, 64, 128, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+        else AVAE_LAUNCH((k_grouped<float, 64, 128, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
     } else if (compute_dtype == AVAE_BF16) { if (tn) AVAE_GO(__bf16, true); else AVAE_GO(__bf16, false); }
     else { if (tn) AVAE_GO(float, true); else AVAE_GO(float, false); }
 #undef AVAE_GO
