@@ -306,6 +306,29 @@ def test_train_steps_equals_single_steps(V, given_eps):
         m.partial_fit_steps([x[:B] for x in X], 2)         # rows must be batch_size x n_steps
 
 
+def test_train_steps_with_conv_modality(V):
+    """The staging-set relocation of the multi-step replays also covers the conv branch (its first im2col reads the
+    staged image): a run of 6 batches (one replay of 4 + 2 single steps) equals 6 single steps, bitwise."""
+    img = dict(make_arch("image", 784, 8, 16, 6), hidden_conv=True, n_hidden_gener_1=16, n_hidden_gener_2=8)
+    jnt = make_arch("joint", 147, 24, 16, 6)
+    rng = np.random.default_rng(13)
+    n, B = 6, 8
+    data = np.concatenate(synth_batch(rng, n * B, [784, 147], [True, False]), axis=1)
+    dev = torch.as_tensor(data).cuda()
+    X = [dev[:, :784], dev[:, 784:]]
+    res = []
+    for many in (False, True):
+        m = V.AssocVariationalAutoEncoder([img, jnt], binary=[True, False], transfer_fct="relu", weights=[50, 1], assoc_lambda=8.0,
+                                          batch_size=B, compute_dtype="bf16", seed=2)
+        if many:
+            m.partial_fit_steps(X, n)
+        else:
+            for i in range(n):
+                m.partial_fit([x[i * B:(i + 1) * B] for x in X])
+        res.append((m.cost_history(n).copy(), m.get_params()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 # ----------------------------------------------------------------------------- inference surface
 def test_transform_generate_reconstruct_rows(V):
     archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
