@@ -83,7 +83,12 @@ template <> __device__ __forceinline__ void store_vec<__bf16, 8>(__bf16* p, cons
     if (nvalid >= 8) {
         typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
         const bf16x8_t t = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
-        *reinterpret_cast<bf16x8_t*>(p) = t;
+        // Written through to memory (sc0 sc1): the big launches leave 17-34 MB of results dirty in L2, which the
+        // end-of-kernel release then has to write back before the next launch may start (3.4 us gap); stores that go
+        // through as they are issued take 2 us off every big forward launch and change nothing for the small ones.
+        typedef __attribute__((ext_vector_type(4))) unsigned u4_;
+        const u4_ raw = __builtin_bit_cast(u4_, t);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(raw) : "memory");
         return;
     }
 #pragma unroll
