@@ -97,3 +97,17 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_bench_accounting_matches_survey_figures():
+    """bench.py's algorithmic work per step (what roofline.achieved is priced with) against the figures of SURVEY.md 8d:
+    train FLOPs per paired sample 7 946 000 (C2) / 87 390 208 (C4), weights only -- bench also counts the bias rows."""
+    import bench
+    for cfg, per_sample in (("c2", 7946000), ("c4", 87390208)):
+        archs, B, dtype, _ = bench.CONFIGS[cfg]
+        work, P = bench.launch_work(archs, B, 2)
+        flops = sum(f for _, f in work.values())
+        assert abs(flops / B - per_sample) / per_sample < 0.01, (cfg, flops / B)
+        assert P == (1468611 if cfg == "c2" else 14900387)
+        # every launch name bench prices is a launch the library reports (names mirror build_training_plan)
+        assert {"prep", "adam", "fwd_head", "fwd_out_loss", "bwd_out", "bwd_dec1_latent", "bwd_head"} <= set(work)
