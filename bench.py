@@ -218,11 +218,11 @@ def main():
     def run(n):
         """n train steps over the resident batches in order (eps: in-kernel Philox stream).  A single replica
         hands runs of consecutive batches over in one submission, as train() does between two reshuffles;
-        under data parallelism the all-reduce sits inside every step, so steps are submitted one by one."""
+        under data parallelism the batches of a run are staged together and every step is backward -> all-reduce -> Adam."""
         i = 0
         while i < n:
             k = i % nb
-            m = 1 if (world > 1 or args.single_step) else min(nb - k, n - i)
+            m = 1 if args.single_step else min(nb - k, n - i)
             if m == 1:
                 model.partial_fit(batches[k], return_cost=False)
             else:
@@ -310,7 +310,7 @@ def main():
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": label, "global_batch": B * world, "per_gpu_batch": B, "n_params": P,
                        "parallelism": "dp%d" % world, "graph": not args.no_graph,
-                       "submission": "per step" if (world > 1 or args.single_step) else "runs of <=16 consecutive resident batches"},
+                       "submission": "per step" if args.single_step else "runs of <=16 consecutive resident batches"},
             "roofline": roof,
             "step_roofline": {"algorithmic_bytes": step_bytes, "algorithmic_flop": step_flop,
                               "hbm_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),

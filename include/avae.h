@@ -124,6 +124,11 @@ int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev,
 int avae_step_backward(avae_handle* h, const float* const* x_dev, const int32_t* x_ld,
                        const float* eps_dev, void* stream);
 int avae_step_apply(avae_handle* h, float* cost_host, void* stream);
+/* The same seam for a run of consecutive batches (layout as in avae_train_steps): ONE staging launch for up to 16
+ * batches, then per step j = 0..n-1: avae_step_backward_staged(j) -> all-reduce -> avae_step_apply. */
+int avae_stage_batches(avae_handle* h, int32_t n_steps, const float* const* x_dev, const int32_t* x_ld,
+                       const float* eps_dev, void* stream);
+int avae_step_backward_staged(avae_handle* h, int32_t j, void* stream);
 int avae_grad_buffer(avae_handle* h, float** dev_ptr, size_t* n_floats);
 /* Costs of the most recent `n` applied steps (oldest first), without having synchronised per step. */
 int avae_cost_history(avae_handle* h, int32_t n, float* host_dst, int64_t* last_step);

@@ -40,6 +40,13 @@ def _worker(rank, port, out_dir, dtype):
         lo, hi = rank * B_LOC, (rank + 1) * B_LOC
         costs = [m.partial_fit([x[lo:hi] for x in X], eps[s][lo:hi]) for s in range(STEPS)]
         ev = m.evaluate_cost([x[lo:hi] for x in X], eps[0][lo:hi])          # summed over ranks inside
+        # the same steps as one run (avae_stage_batches + avae_step_backward_staged): must be bitwise the same
+        m2 = AssocVariationalAutoEncoder(ARCHS, batch_size=B_LOC, compute_dtype=dtype, device=0, data_parallel=True, **KW)
+        run_x = [np.concatenate([x[lo:hi]] * STEPS) for x in X]
+        run_eps = np.concatenate([eps[s][lo:hi] for s in range(STEPS)])
+        last = m2.partial_fit_steps(run_x, STEPS, run_eps)
+        assert last == costs[-1] and np.array_equal(m2.get_params(), m.get_params())
+        assert np.array_equal(m2.cost_history(STEPS), np.array(costs, dtype=np.float32))
         np.savez(os.path.join(out_dir, "r%d.npz" % rank), costs=np.array(costs), params=m.get_params(), ev=ev)
     finally:
         dist.destroy_process_group()

@@ -26,7 +26,7 @@ LIB_PATH = os.path.join(_HERE, "libavae.so")
 SYMBOLS = [
     "avae_workspace_bytes", "avae_create", "avae_destroy", "avae_last_error", "avae_param_count",
     "avae_get_params", "avae_set_params", "avae_get_grads", "avae_get_opt_state", "avae_set_opt_state",
-    "avae_train_step", "avae_train_steps", "avae_step_backward", "avae_step_apply", "avae_grad_buffer", "avae_cost_history",
+    "avae_train_step", "avae_train_steps", "avae_step_backward", "avae_step_apply", "avae_stage_batches", "avae_step_backward_staged", "avae_grad_buffer", "avae_cost_history",
     "avae_eval_cost", "avae_encode", "avae_decode", "avae_reconstruct", "avae_save", "avae_load",
     "avae_synchronize", "avae_timing_enable", "avae_timing_report", "avae_debug_fetch",
 ]
@@ -81,6 +81,8 @@ def lib():
             L.avae_train_steps.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), vp, fp, vp]
             L.avae_step_backward.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), vp, vp]
             L.avae_step_apply.argtypes = [vp, fp, vp]
+            L.avae_stage_batches.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), vp, vp]
+            L.avae_step_backward_staged.argtypes = [vp, i32, vp]
             L.avae_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
             L.avae_cost_history.argtypes = [vp, i32, vp, C.POINTER(C.c_int64)]
             L.avae_eval_cost.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), vp, fp, vp]

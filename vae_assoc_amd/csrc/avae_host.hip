@@ -134,6 +134,7 @@ struct avae_handle {
     hipGraphExec_t g_multi[2] = {nullptr, nullptr};   // kMultiSizes[i] whole steps per replay (avae_train_steps)
     hipGraph_t g_full_graph = nullptr, g_multi_graph[2] = {nullptr, nullptr};   // templates, kept: their staging-kernel nodes are re-parameterised per replay
     hipGraphNode_t g_full_prep = nullptr, g_multi_prep[2] = {nullptr, nullptr};
+    std::vector<hipGraphExec_t> g_bwd_set;  // data-parallel runs: forward + backward + wgrad on staging set j (captured on first use)
 
     bool timing = false;
     bool debug_sync = false;
@@ -1193,6 +1194,7 @@ void avae_destroy(avae_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     for (hipGraphExec_t g : {h->g_full, h->g_multi[0], h->g_multi[1], h->g_bwd, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
+    for (hipGraphExec_t g : h->g_bwd_set) if (g) (void)hipGraphExecDestroy(g);
     for (hipGraph_t g : {h->g_full_graph, h->g_multi_graph[0], h->g_multi_graph[1]}) if (g) (void)hipGraphDestroy(g);
     for (TimingRec& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -1259,6 +1261,39 @@ int avae_step_apply(avae_handle* h, float* cost_host, void* stream) {
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         do_apply(h, s);
         fetch_cost(h, cost_host, true, s);
+    });
+}
+
+// Data-parallel runs of consecutive batches: one staging launch for up to kMultiSteps batches, then per step
+// backward on its staging set -> (caller's all-reduce) -> apply.
+int avae_stage_batches(avae_handle* h, int32_t n_steps, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, void* stream) {
+    return guarded(h, [&] {
+        if (n_steps < 1 || n_steps > kMultiSteps) throw Err("avae_stage_batches: n_steps must be in [1," + std::to_string(kMultiSteps) + "]");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const PrepArgs a = make_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, n_steps);
+        Timed t(h, s, "prep");
+        launch_prep(h->cfg.compute_dtype, a, s);
+    });
+}
+
+int avae_step_backward_staged(avae_handle* h, int32_t j, void* stream) {
+    return guarded(h, [&] {
+        if (j < 0 || j >= kMultiSteps) throw Err("avae_step_backward_staged: staging set out of range");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        auto body = [&](hipStream_t cs) {
+            for (const std::vector<Launch>* ls : {&h->fwd, &h->bwd, &h->wgrad}) {
+                std::vector<Launch> moved;
+                for (const Launch& L : *ls) moved.push_back(relocated(h, L, j));
+                run_launches(h, moved, cs);
+            }
+        };
+        if (h->cfg.use_graph && !h->timing) {
+            if (h->g_bwd_set.empty()) h->g_bwd_set.assign(kMultiSteps, nullptr);
+            if (!h->g_bwd_set[j]) h->g_bwd_set[j] = capture(h, body);
+            HIP_OK(hipGraphLaunch(h->g_bwd_set[j], s));
+        } else {
+            body(s);
+        }
     });
 }
 

@@ -334,11 +334,19 @@ class AssocVariationalAutoEncoder(object):
         loop does with ``DataSet.next_batch``'s consecutive slices (vae_assoc.py:541-550).  Returns the
         last step's cost; every step's cost is in ``cost_history``."""
         n_steps = int(n_steps)
-        if self._sync is not None and self._sync.world_size > 1:      # the all-reduce sits between backward and Adam
-            B, cost = self.batch_size, None
-            for i in range(n_steps):
-                cost = self.partial_fit([x[i * B:(i + 1) * B] for x in X], None if eps is None else eps[i * B:(i + 1) * B],
-                                        return_cost and i == n_steps - 1)
+        if self._sync is not None and self._sync.world_size > 1:
+            # the all-reduce sits between backward and Adam of every step; the batches are staged 16 at a time
+            ts, ptrs, lds, e = self._batch_args(X, eps, n_steps)
+            B, cost, st = self.batch_size, None, self._stream()
+            for i0 in range(0, n_steps, 16):
+                n = min(16, n_steps - i0)
+                p_i = (C.c_void_p * len(ts))(*[t.data_ptr() + i0 * B * t.stride(0) * 4 for t in ts])
+                e_i = (e.data_ptr() + i0 * B * self.n_z * 4) if e is not None else None
+                _capi.check(self._h, self._L.avae_stage_batches(self._h, n, p_i, lds, e_i, st), "avae_stage_batches")
+                for j in range(n):
+                    _capi.check(self._h, self._L.avae_step_backward_staged(self._h, j, st), "avae_step_backward_staged")
+                    self._sync.all_reduce_(self._grad_view)
+                    cost = self._apply(return_cost and i0 + j == n_steps - 1)
             return cost
         ts, ptrs, lds, e = self._batch_args(X, eps, n_steps)
         cost = C.c_float(0.0)
