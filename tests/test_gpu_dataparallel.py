@@ -74,3 +74,20 @@ def test_two_hip_replicas_match_single_replica_global_batch(tmp_path, dtype):
     assert abs(float(r[0]["ev"]) - ref_ev) <= tol * abs(ref_ev)
     # fp32: weights track the global-batch run up to Adam's amplification of rounding-level gradient differences
     assert np.abs(r[0]["params"] - full.get_params()).max() <= (2e-4 if dtype == "fp32" else 7.5e-3)
+
+
+def test_rccl_backend_collective_on_the_gradient_view():
+    """The collective the data-parallel path issues, on the RCCL backend (one rank is all a one-GPU box offers):
+    backward graph -> dist.all_reduce of the float32 view into the library's workspace -> Adam, over a run of steps,
+    leaves the weights bitwise equal to the single-replica run (tools/nccl_view_check.py, in a process of its own)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_view_check.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "weights equal to the single-replica run: True" in r.stdout
