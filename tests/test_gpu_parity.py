@@ -220,6 +220,32 @@ def test_shapes_and_options(V, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_random_shapes(V, dtype):
+    """25 seeded random models (1-4 modalities, 1-3 hidden layers, widths 1-150, n_z 1-64, batch 1-200, every activation,
+    mixed Bernoulli / Gaussian): one train step each against the oracle at the tolerances of check_step_parity.  Odd sizes are
+    where a tiling mistake would read or write out of range."""
+    rng = np.random.default_rng(2026)
+    acts = ["relu", "softplus", "tanh", "sigmoid", "identity"]
+    for case in range(25):
+        M = int(rng.integers(1, 5))
+        nz = int(rng.choice([1, 2, 3, 5, 8, 20, 31, 33, 64]))
+        B = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 65, 100, 129, 200]))
+        archs, binary, w = [], [], []
+        for m in range(M):
+            hs = [int(rng.integers(1, 151)) for _ in range(int(rng.integers(1, 4)))]
+            archs.append(make_arch("m%d" % m, int(rng.integers(1, 301)), 0, 0, nz, n_hidden=hs))
+            binary.append(bool(rng.integers(0, 2)))
+            w.append(float(rng.choice([0.5, 1.0, 3.0, 50.0])))
+        lam = float(rng.choice([0.0, 1e-5, 0.3, 8.0]))
+        act = acts[case % len(acts)]
+        try:
+            check_step_parity(V, archs, binary, w, lam, act, B, dtype, steps=1, seed=100 + case)
+        except AssertionError as e:
+            raise AssertionError("case %d: M=%d nz=%d B=%d act=%s archs=%s: %s" % (
+                case, M, nz, B, act, [(a["n_input"], a["n_hidden"]) for a in archs], e))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_conv_deconv_branch(V, dtype):
     """hidden_conv=True image modality (vae_assoc.py:169-210,249-291; deconv.py) paired with the MLP joint
     modality: the commented-out configuration of vae_assoc_ujichar_img_jnt.py:72-80 (depths 16/64, 64/16)."""
