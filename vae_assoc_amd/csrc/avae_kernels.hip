@@ -432,6 +432,10 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
 #endif
 
     const WorkItem w = args.items[blockIdx.y];                    // one burst of scalar loads from the kernarg segment
+    // ... and it has to BE one burst: left alone, the compiler fetches the few fields the tile-index branch below needs,
+    // waits, and only then fetches the operand pointers -- two kernel-argument round trips (~0.25 us each) before the
+    // first load of every workgroup.  Naming the fields here puts all their s_loads ahead of the first wait.
+    asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.aux0), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.ldx), "s"(lds_bytes));
     // XCD-aware tile order inside the item: hardware deals workgroups round-robin over the 8 XCDs
     // (private 4 MiB L2 each) in linear order y*grid_x + x, and grid_x is a multiple of 8, so x%8 names the XCD group.
     // Each group gets one contiguous chunk of the item's tile list (tiles that share A row panels /
