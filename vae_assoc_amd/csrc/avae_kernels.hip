@@ -388,7 +388,8 @@ template <int BM, int BN, int RING> struct TileSmem {
 };
 // tile_cfg: 0 = 64x64 tile, 4-stage ring; 1 = 128x128 tile, 2-stage ring, two workgroups per CU;
 //           2 = 256x128 tile, 3-stage ring, one workgroup per CU (big single-C-tile kinds only)
-//           3 = 32x64 tile, 4-stage ring (NT launches with too few 64x64 tiles to occupy the chip)
+//           3 = 32x64 tile, 4-stage ring (NT launches with too few 64x64 tiles to occupy the chip; a 6-stage ring is slower:
+//               issuing five tiles up front costs more than the latency it hides, 69.1 vs 67.1 us/step on C2)
 //           4 = 64x128 tile, 4-stage ring (wide-latent head / latent-dgrad launches with few tiles: three K tiles in
 //               flight instead of one, twice the workgroups of cfg 1)
 int tile_lds_bytes(int tile_cfg, bool two_c_tiles) {
@@ -583,15 +584,13 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     for (int kt = 0; kt < nk; ++kt) {
         AVAE_LT0()
         const int rem = nk - 1 - kt;           // tiles issued behind kt: min(rem, RING - 2); vmcnt needs an immediate
-        if constexpr (RING == 2) {
-            AVAE_WAIT(0);
-        } else if constexpr (RING == 3) {
-            if (rem >= 1) AVAE_WAIT(NCH);
-            else AVAE_WAIT(0);
-        } else {
-            static_assert(RING == 4, "wait ladder written for RING 2, 3 and 4");
-            if (rem >= 2) AVAE_WAIT(2 * NCH);
-            else if (rem == 1) AVAE_WAIT(NCH);
+        {   // tile kt has landed once at most min(rem, RING-2) younger tiles are still in flight
+            static_assert(RING >= 2 && RING <= 6, "wait ladder written for rings of 2 to 6 stages");
+            const int nb = rem < RING - 2 ? rem : RING - 2;
+            if (RING >= 6 && nb == 4) AVAE_WAIT(4 * NCH);
+            else if (RING >= 5 && nb == 3) AVAE_WAIT(3 * NCH);
+            else if (RING >= 4 && nb == 2) AVAE_WAIT(2 * NCH);
+            else if (RING >= 3 && nb == 1) AVAE_WAIT(NCH);
             else AVAE_WAIT(0);
         }
         AVAE_LT(0)
