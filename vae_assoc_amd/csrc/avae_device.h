@@ -1,7 +1,7 @@
 // Device-visible descriptors shared by the host planner (avae_host.hip) and the gfx950 kernels
 // (avae_kernels.hip).  A training step is a fixed list of launches; each launch runs ONE
-// grouped kernel over a table of work items that lives in HBM and never changes after
-// avae_create, which is what lets the whole step be captured once as a hipGraph.
+// grouped kernel over a table of work items passed by value in its kernel arguments; nothing in it
+// changes after avae_create, which is what lets the whole step be captured once as a hipGraph.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,15 +15,16 @@ constexpr int kRowAlign = 256;         // row counts of GEMM operands are padded
 constexpr int kLatentRows = 16;        // rows per latent work-item tile (many small blocks: the item is latency-bound)
 constexpr int kCostHist = 4096;        // ring of per-step costs kept on the device
 
-// Work-item kinds.  All GEMM kinds compute C[M,N] = sum_k A[m][k] * B[n][k] with both operands
-// K-contiguous ("NT" form) and differ only in the LDS-staged epilogue.
+// Work-item kinds.  Forward / dgrad kinds compute C[M,N] = sum_k A[m][k] * B[n][k] ("NT": both operands K-contiguous),
+// K_WGRAD computes C[M,N] = sum_k A[k][m] * B[k][n] ("TN": both operands as stored, K = batch); they differ otherwise
+// only in the LDS-staged epilogue.  Every result is stored once, row-major.
 enum Kind : int {
-    K_FWD_HIDDEN = 0,    // Y = act(X_aug . W_aug)                      -> Y, Y^T          (vae_assoc.py:187,203,259,282)
-    K_FWD_HEAD = 1,      // [mu|lv] = H_aug . Whead_aug; z = mu+exp(lv/2)*eps -> mulv, Z, Z^T (:217-221,:102-103)
-    K_FWD_OUT_LOSS = 2,  // logits; recon loss + dLoss/dlogits         -> dA, dA^T, cost partial (:293-303,:321-328)
+    K_FWD_HIDDEN = 0,    // Y = act(X_aug . W_aug)                      -> Y               (vae_assoc.py:187,203,259,282)
+    K_FWD_HEAD = 1,      // [mu|lv] = H_aug . Whead_aug; z = mu+exp(lv/2)*eps -> mulv, Z   (:217-221,:102-103)
+    K_FWD_OUT_LOSS = 2,  // logits; recon loss + dLoss/dlogits         -> dA, cost partial (:293-303,:321-328)
     K_FWD_OUT_STORE = 3, // x_hat = sigmoid(logits) | logits           -> fp32 (inference)
-    K_DGRAD_HIDDEN = 4,  // dA_prev = (dA . W^T) * act'(Y_prev)        -> dA_prev, dA_prev^T
-    K_DGRAD_LATENT = 5,  // dz = dA . V1^T; dmu, dlv via reparam + static latent grads -> dH, dH^T
+    K_DGRAD_HIDDEN = 4,  // dA_prev = (dA . W^T) * act'(Y_prev)        -> dA_prev
+    K_DGRAD_LATENT = 5,  // dz = dA . V1^T; dmu, dlv via reparam + static latent grads -> dH
     K_WGRAD = 6,         // dW_aug = X_aug^T . dA (bias grad = last row) -> fp32 gradient
     K_DGRAD_F32 = 10,    // dP = dA . W^T stored as fp32 (conv branch: patch gradients, summed by k_col2im)
     K_LATENT = 7,        // KL(q||N(0,I)) + association penalty: cost partials + static (mu,lv) grads (:335-366)
@@ -108,7 +109,7 @@ struct AdamArgs {
     const float* cost_src;   // grad[cost slot]
 };
 
-// Input staging ("prep"): fp32 rows -> compute-dtype row-major + transposed copies (+ fp32 copy),
+// Input staging ("prep"): fp32 rows -> compute-dtype copy (+ exact fp32 copy for the losses),
 // and the eps tensor (copied from the caller or generated with Philox4x32-10).
 struct PrepSeg {
     const float* src; int src_ld;
