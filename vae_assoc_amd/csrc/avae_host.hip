@@ -302,9 +302,9 @@ void plan_memory(avae_handle* h) {
     h->off_m = b.take(pint * 4);
     h->off_v = b.take(pint * 4);
     h->off_g = b.take((pint + 64) * 4);      // + cost slot (element P_int), padded
-    // cost partial slots: one per output-loss tile (the smallest tile, 32x64, bounds the count) + latent tiles
+    // cost partial slots: one per output-loss tile (the smallest tile, 32x32, bounds the count) + latent tiles
     int slots = (B + kLatentRows - 1) / kLatentRows;
-    for (int m = 0; m < h->M; ++m) slots += ((B + 31) / 32) * ((h->mods[m].n_in + 63) / 64);
+    for (int m = 0; m < h->M; ++m) slots += ((B + 31) / 32) * ((h->mods[m].n_in + 31) / 32);
     h->n_partial = slots;
     h->off_partial = b.take((size_t)slots * 4);
     h->off_state = b.take(sizeof(DevState));
@@ -550,6 +550,9 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
             nt = nt && w.kind != K_WGRAD && w.kind != K_DGRAD_F32;
         }
         if (nt && t64 > 0 && t64 <= 128) L.cfg = 3;
+        bool head = false;
+        for (int i = first; i < first + count; ++i) head = head || items[i].kind == K_FWD_HEAD || items[i].kind == K_DGRAD_LATENT;
+        if (L.cfg == 3 && !head && !std::getenv("AVAE_NO_32x32")) L.cfg = 5;      // no kind that needs 2*n_z columns in one tile
     }
     if (L.cfg == 1 && need128 && !std::getenv("AVAE_NO_64x128")) {      // wide-latent head launches: few tiles, K loop = load latency
         long t = 0;
@@ -561,7 +564,8 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         }
         if (nt && t <= 256) L.cfg = 4;
     }
-    const int T = (L.cfg == 1 || L.cfg == 2 || L.cfg == 4) ? 128 : 64, TM = L.cfg == 2 ? 256 : L.cfg == 3 ? 32 : L.cfg == 4 ? 64 : T;
+    const int T = (L.cfg == 1 || L.cfg == 2 || L.cfg == 4) ? 128 : L.cfg == 5 ? 32 : 64;
+    const int TM = L.cfg == 2 ? 256 : (L.cfg == 3 || L.cfg == 5) ? 32 : L.cfg == 4 ? 64 : T;
     int max_tiles = 1;
     for (int i = first; i < first + count; ++i) {
         WorkItem& w = items[i];

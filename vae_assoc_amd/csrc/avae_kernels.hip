@@ -247,7 +247,9 @@ template <typename OT, typename AT, bool HAS_AUX, bool WRITEBACK, int BM, int BN
 __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT* aux, int ldx,
                                           int M, int N, int m0, int n0, Op op) {
     constexpr int VW = Vec16<OT>::VW;                     // elements per 16-byte store
-    constexpr int LDC = BN + 4, QC = BN / VW, NQT = BM * QC / NT;
+    constexpr int LDC = BN + 4, QC = BN / VW, NG = BM * QC;   // NG groups of VW elements in the tile
+    constexpr int NQT = (NG + NT - 1) / NT;               // groups per thread (the smallest tile has fewer groups than threads)
+    constexpr bool PARTIAL = NG % NT != 0;
     constexpr int NQ = NQT < 32 / VW ? NQT : 32 / VW;     // groups handled together: <= 32 elements per array in flight
     static_assert(NQT % NQ == 0, "tile / thread mapping");
     const int tid = threadIdx.x;
@@ -255,7 +257,7 @@ __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT*
         float c[NQ][VW], a[NQ][VW];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + (q0 + q) * NT, row = idx / QC, c0 = (idx - row * QC) * VW;
+            const int idx = PARTIAL ? min(tid + (q0 + q) * NT, NG - 1) : tid + (q0 + q) * NT, row = idx / QC, c0 = (idx - row * QC) * VW;
 #pragma unroll
             for (int h = 0; h < VW / 4; ++h) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + cs_idx<LDC>(row, c0 + 4 * h));
@@ -271,11 +273,13 @@ __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT*
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + (q0 + q) * NT, row = idx / QC, c0 = (idx - row * QC) * VW;
-            const bool rok = m0 + row < M;
+            const int raw = tid + (q0 + q) * NT;
+            const bool mine = !PARTIAL || raw < NG;       // threads beyond the tile's last group compute on a clamped copy, store nothing
+            const int idx = PARTIAL ? min(raw, NG - 1) : raw, row = idx / QC, c0 = (idx - row * QC) * VW;
+            const bool rok = mine && m0 + row < M;
 #pragma unroll
             for (int e = 0; e < VW; ++e) c[q][e] = op(c[q][e], a[q][e], rok && (n0 + c0 + e < N));
-            if (WRITEBACK) {
+            if (WRITEBACK && mine) {
 #pragma unroll
                 for (int h = 0; h < VW / 4; ++h)
                     *reinterpret_cast<f32x4*>(Cs + cs_idx<LDC>(row, c0 + 4 * h)) = f32x4{c[q][4 * h], c[q][4 * h + 1], c[q][4 * h + 2], c[q][4 * h + 3]};
@@ -283,9 +287,10 @@ __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT*
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + (q0 + q) * NT, row = idx / QC, c0 = (idx - row * QC) * VW;
+            const int raw = tid + (q0 + q) * NT;
+            const int idx = PARTIAL ? min(raw, NG - 1) : raw, row = idx / QC, c0 = (idx - row * QC) * VW;
             const int grow = m0 + row, gcol = n0 + c0;
-            if (grow < M && gcol < N) store_vec<OT, VW>(out + (size_t)grow * ld0 + gcol, c[q], N - gcol);
+            if ((!PARTIAL || raw < NG) && grow < M && gcol < N) store_vec<OT, VW>(out + (size_t)grow * ld0 + gcol, c[q], N - gcol);
         }
     }
 }
@@ -392,7 +397,10 @@ template <int BM, int BN, int RING> struct TileSmem {
 //               issuing five tiles up front costs more than the latency it hides, 69.1 vs 67.1 us/step on C2)
 //           4 = 64x128 tile, 4-stage ring (wide-latent head / latent-dgrad launches with few tiles: three K tiles in
 //               flight instead of one, twice the workgroups of cfg 1)
+//           5 = 32x32 tile, 4-stage ring (as 3, for launches without head kinds: a wave issues 2 refill pieces per K tile
+//               instead of 3, and the issue cost of those pieces is what paces the K loop of a lone workgroup)
 int tile_lds_bytes(int tile_cfg, bool two_c_tiles) {
+    if (tile_cfg == 5) return TileSmem<32, 32, 4>::kStages + 64;
     if (tile_cfg == 4) {
         const int st = TileSmem<64, 128, 4>::kStages, c4 = TileSmem<64, 128, 4>::kC * (two_c_tiles ? 2 : 1);
         return (st > c4 ? st : c4) + 64;
@@ -638,7 +646,7 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     switch (w.kind) {
     case K_FWD_HIDDEN: {
         CT* Y = reinterpret_cast<CT*>(w.out0);
-        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, false, true, BM, BN, NT>(Cs, Y, w.ld0, (const CT*)nullptr, 4, M, N, m0, n0,
+        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, false, false, BM, BN, NT>(Cs, Y, w.ld0, (const CT*)nullptr, 4, M, N, m0, n0,
             [](float c, float, bool) { return act_fwd_t<ACT>(c); })))
         AVAE_STAMP(6)
     } break;
@@ -694,7 +702,7 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
         const float sc = w.scale;
         float csum = 0.0f;
         if (w.binary) {
-            tile_pass<CT, float, true, true, BM, BN>(Cs, dA, w.ld0, X, w.ldx, M, N, m0, n0,
+            tile_pass<CT, float, true, false, BM, BN>(Cs, dA, w.ld0, X, w.ldx, M, N, m0, n0,
                 [&csum, sc](float a, float x, bool ok) {
                     const float en = fexp(-a), p = frcp(1.0f + en);
                     const float lp = 1e-3f + p, lq = 1e-3f + 1.0f - p;
@@ -704,7 +712,7 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
                     return ok ? da : 0.0f;
                 });
         } else {
-            tile_pass<CT, float, true, true, BM, BN>(Cs, dA, w.ld0, X, w.ldx, M, N, m0, n0,
+            tile_pass<CT, float, true, false, BM, BN>(Cs, dA, w.ld0, X, w.ldx, M, N, m0, n0,
                 [&csum, sc](float a, float x, bool ok) {
                     const float df = a - x;
                     csum += ok ? sc * 0.5f * df * df : 0.0f;
@@ -729,7 +737,7 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     case K_DGRAD_HIDDEN: {
         CT* dX = reinterpret_cast<CT*>(w.out0);
         const CT* Yp = reinterpret_cast<const CT*>(w.aux0);
-        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, true, true, BM, BN, NT>(Cs, dX, w.ld0, Yp, w.ldx, M, N, m0, n0,
+        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, true, false, BM, BN, NT>(Cs, dX, w.ld0, Yp, w.ldx, M, N, m0, n0,
             [](float c, float y, bool) { return c * act_bwd_t<ACT>(y); })))
     } break;
     case K_DGRAD_LATENT: {
@@ -828,6 +836,7 @@ void launch_grouped(int compute_dtype, int tile_cfg, bool tn, const LaunchArgs& 
         set_max_lds(k_grouped<float, 64, 64, 4>); set_max_lds(k_grouped<float, 128, 128, 2>); set_max_lds(k_grouped<float, 256, 128, 3, 8>);
         set_max_lds(k_grouped<__bf16, 32, 64, 4>); set_max_lds(k_grouped<float, 32, 64, 4>);
         set_max_lds(k_grouped<__bf16, 64, 128, 4>); set_max_lds(k_grouped<float, 64, 128, 4>);
+        set_max_lds(k_grouped<__bf16, 32, 32, 4>); set_max_lds(k_grouped<float, 32, 32, 4>);
         set_max_lds(k_grouped<__bf16, 64, 64, 4, 4, true>); set_max_lds(k_grouped<__bf16, 128, 128, 2, 4, true>); set_max_lds(k_grouped<__bf16, 256, 128, 3, 8, true>);
         set_max_lds(k_grouped<float, 64, 64, 4, 4, true>); set_max_lds(k_grouped<float, 128, 128, 2, 4, true>); set_max_lds(k_grouped<float, 256, 128, 3, 8, true>);
         return true;
@@ -843,6 +852,9 @@ void launch_grouped(int compute_dtype, int tile_cfg, bool tn, const LaunchArgs& 
     if (tile_cfg == 3) {      // NT only
         if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_grouped<__bf16, 32, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
         else AVAE_LAUNCH((k_grouped<float, 32, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+    } else if (tile_cfg == 5) {      // NT only
+        if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_grouped<__bf16, 32, 32, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
+        else AVAE_LAUNCH((k_grouped<float, 32, 32, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
     } else if (tile_cfg == 4) {      // NT only
         if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_grouped<__bf16, 64, 128, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
         else AVAE_LAUNCH((k_grouped<float, 64, 128, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
