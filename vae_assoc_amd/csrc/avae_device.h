@@ -40,6 +40,8 @@ struct WorkItem {
     int ld0, ld1, ldx;
     int nz;
     int binary;
+    int ksplit, kchunk;      // K_WGRAD with a long K (conv stages: K = batch x output pixels): the K range is cut into ksplit
+                             // chunks of kchunk K tiles, chunk s writing its own fp32 slice out1 + s*M*ld0 (summed by k_reduce)
     int slot_base;           // first cost-partial slot written by this item
     int n_slots;             // K_COST: number of partial slots to sum
     int n_mod;               // K_LATENT
@@ -137,6 +139,11 @@ struct PrepArgs {
     long long set_stride;
 };
 
+// Fixed-order sum of the split-K slices of a weight gradient: dst[i] = sum_s src[s*stride + i]  (no atomics: reproducible).
+struct ReduceSeg { float* dst; const float* src; int n, parts; long long stride; int block_base, pad; };
+constexpr int kMaxReduceSegs = 24;
+struct ReduceArgs { ReduceSeg seg[kMaxReduceSegs]; int n_seg; };
+
 // Conv / transposed-conv layers (reference vae_assoc.py:169-199,249-278, deconv.py:107) run on the
 // same GEMM kernel through explicit patch matrices.  One geometry covers both directions:
 //   P[(b,oh,ow)][(kh,kw,ci)] = X[b, (oh*so + kh - pad)/d, (ow*so + kw - pad)/d, ci]   (0 if not divisible / out of range)
@@ -187,5 +194,6 @@ void launch_adam(int compute_dtype, const AdamArgs& a, int n_blocks, hipStream_t
 void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s);
 const void* prep_kernel(int compute_dtype);          // for hipGraphExecKernelNodeSetParams on the captured staging node
 void launch_fill(void* base, int elem_bytes, unsigned bits, long long start, long long stride, int count, hipStream_t s);
+void launch_reduce(const ReduceArgs& a, int n_blocks, hipStream_t s);
 
 }  // namespace avae

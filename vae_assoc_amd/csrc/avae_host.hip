@@ -72,6 +72,8 @@ struct ConvStage {
     Act dY;                // gradient w.r.t. the stage's pre-activation output (row-major + transposed)
     size_t dP = 0;         // fp32 patch gradients [rows][lddp]
     int lddp = 0;
+    int ksplit = 1, kchunk = 0;    // weight gradient: K = rows is cut into ksplit chunks of kchunk K tiles (see WorkItem)
+    size_t part = 0;       // fp32 slices [ksplit][K+1][d.ld] of the split weight gradient
 };
 
 struct Mod {
@@ -89,13 +91,14 @@ struct Mod {
 
 struct Launch {
     std::string name;
-    int type = 0;          // 0: grouped GEMM kernel, 1: k_gather (im2col), 2: k_col2im
+    int type = 0;          // 0: grouped GEMM kernel, 1: k_gather (im2col), 2: k_col2im, 3: k_reduce (split-K slices -> gradient)
     int cfg = 0, first = 0, count = 0, blocks = 0, lds = 0;
     int grid_x = 1, grid_y = 1;   // grouped kernel: tile slot x item
     bool tn = false;              // K-major operands (the weight-gradient launches)
     LaunchArgs args{};
     GatherArgs ga{};
     Col2imArgs ca{};
+    ReduceArgs ra{};
 };
 
 struct TimingRec { hipEvent_t a, b; int launch_name; };
@@ -267,6 +270,16 @@ void plan_memory(avae_handle* h) {
                 }
                 st.lddp = (int)rup(K, 8);
                 st.dP = b.take((size_t)rows * st.lddp * 4);
+                {   // a conv stage's weight gradient sums over batch x output pixels (up to 200 704 rows) into a few tiles:
+                    // cut that K range so that the launch has a few hundred workgroups of at least 8 K tiles each
+                    const int steps = (int)(rup(rows, KU) / KU), tiles = ((K + 1 + 63) / 64) * ((Cout + 63) / 64);
+                    int split = std::min(steps / 8, (512 + tiles - 1) / tiles);
+                    if (split > 1) {
+                        st.kchunk = (steps + split - 1) / split;
+                        st.ksplit = (steps + st.kchunk - 1) / st.kchunk;
+                        st.part = b.take((size_t)st.ksplit * (K + 1) * st.d.ld * 4);
+                    }
+                }
                 pflat += (size_t)K * Cout + (flat == 0 ? 0 : Cout);
                 return st;
             };
@@ -487,6 +500,11 @@ struct Builder {
         w.out0 = h->grad() + d.master; w.ld0 = d.ld;
         return w;
     }
+    WorkItem wgrad_stage(const ConvStage& st, const Act& dA) {
+        WorkItem w = wgrad(st.P, st.d, dA);
+        if (st.ksplit > 1) { w.ksplit = st.ksplit; w.kchunk = st.kchunk; w.out1 = p<void>(st.part); }
+        return w;
+    }
     WorkItem latent() {
         WorkItem w;
         std::memset(&w, 0, sizeof(w));
@@ -581,7 +599,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
             w.tiles_m = w.tiles_n = 1;
             w.n_slots = *next_slot;
         }
-        max_tiles = std::max(max_tiles, w.tiles_m * w.tiles_n);
+        max_tiles = std::max(max_tiles, w.tiles_m * w.tiles_n * (w.kind == K_WGRAD && w.ksplit > 1 ? w.ksplit : 1));
     }
     // grid: x = tile slot (multiple of 8: the kernel's XCD-aware tile order needs it), y = item
     L.grid_x = (max_tiles + 7) & ~7; L.grid_y = count;
@@ -728,10 +746,10 @@ void build_training_plan(avae_handle* h) {
         std::vector<WorkItem> wg;
         for (Mod& md : h->mods) {
             if (md.conv) {
-                wg.push_back(bd.wgrad(md.cdec[4].P, md.cdec[4].d, md.dO));
-                for (int i = 3; i >= 0; --i) wg.push_back(bd.wgrad(md.cdec[i].P, md.cdec[i].d, md.cdec[i].dY));
-                wg.push_back(bd.wgrad(md.cenc[3].P, md.cenc[3].d, md.dH));
-                for (int i = 2; i >= 0; --i) wg.push_back(bd.wgrad(md.cenc[i].P, md.cenc[i].d, md.cenc[i].dY));
+                wg.push_back(bd.wgrad_stage(md.cdec[4], md.dO));
+                for (int i = 3; i >= 0; --i) wg.push_back(bd.wgrad_stage(md.cdec[i], md.cdec[i].dY));
+                wg.push_back(bd.wgrad_stage(md.cenc[3], md.dH));
+                for (int i = 2; i >= 0; --i) wg.push_back(bd.wgrad_stage(md.cenc[i], md.cenc[i].dY));
                 continue;
             }
             wg.push_back(bd.wgrad(md.D.back(), md.outl, md.dO));
@@ -762,6 +780,20 @@ void build_training_plan(avae_handle* h) {
             group("wgrad" + (chunks.size() > 1 ? std::to_string(c + 1) : std::string()), h->wgrad,
                   [&] { for (const WorkItem& w : chunks[c]) h->items.push_back(w); });
             h->wgrad.back().tn = true;
+        }
+        {   // the split-K slices of the conv stages' weight gradients -> the gradient buffer, in fixed order
+            Launch R;
+            R.name = "wgrad_reduce"; R.type = 3;
+            int base = 0;
+            for (const WorkItem& w : wg) if (w.ksplit > 1) {
+                if (R.ra.n_seg >= kMaxReduceSegs) throw Err("internal error: too many split weight gradients");
+                ReduceSeg& g = R.ra.seg[R.ra.n_seg++];
+                g.dst = reinterpret_cast<float*>(w.out0); g.src = reinterpret_cast<const float*>(w.out1);
+                g.n = w.M * w.ld0; g.parts = w.ksplit; g.stride = (long long)w.M * w.ld0;
+                g.block_base = base; base += (g.n / 4 + kThreads - 1) / kThreads;
+            }
+            R.blocks = base;
+            if (base > 0) h->wgrad.push_back(R);
         }
     }
     // ---- eval: forward launches + a lone cost reduction that does not bump the step
@@ -880,6 +912,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
 #endif
         if (L.type == 1) launch_gather(h->cfg.compute_dtype, L.ga, L.blocks, s);
         else if (L.type == 2) launch_col2im(h->cfg.compute_dtype, L.ca, L.blocks, s);
+        else if (L.type == 3) launch_reduce(L.ra, L.blocks, s);
         else launch_grouped(h->cfg.compute_dtype, L.cfg, L.tn, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to
             std::fprintf(stderr, "[avae] launch %s type=%d cfg=%d items=%d blocks=%d\n", L.name.c_str(), L.type, L.cfg, L.count, L.blocks);

@@ -452,10 +452,14 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     // and light items balanced.  Bijective for any tile count; only speed depends on it.
     int t;
     {
-        const int local = blockIdx.x, nt = w.tiles_m * w.tiles_n;
+        const int local = blockIdx.x, nt = w.tiles_m * w.tiles_n * (TN && w.ksplit > 1 ? w.ksplit : 1);
         const int q = nt >> 3, r = nt & 7, xcd = local & 7, j = local >> 3;
         if (j >= q + (xcd < r ? 1 : 0)) return;                   // padding block behind the item's last tile
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    int ks = 0;                  // split-K chunk of this workgroup (weight gradients with a long K only)
+    if constexpr (TN) {
+        if (w.ksplit > 1) { const int per = w.tiles_m * w.tiles_n; ks = t / per; t -= ks * per; }
     }
     constexpr int NT = NW * 64;
     // The two non-GEMM kinds are handled at the END of the kernel: their bodies are large (cost_item drags in a
@@ -480,7 +484,11 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     const unsigned char* Bg = reinterpret_cast<const unsigned char*>(w.B) + (TN ? (size_t)n0 * ES : (size_t)n0 * w.ldb * ES);
     const size_t lda_b = (size_t)w.lda * ES, ldb_b = (size_t)w.ldb * ES;
     constexpr int EPR = kTileBytesK / ES;          // elements per 128-byte image row = K extent of one stage
-    const int nk = (w.K * ES) / kTileBytesK;
+    int nk = (w.K * ES) / kTileBytesK;
+    int k_first = 0;             // first K tile of this workgroup
+    if constexpr (TN) {
+        if (w.ksplit > 1) { k_first = ks * w.kchunk; nk = min(w.kchunk, nk - k_first); }
+    }
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -511,8 +519,8 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
             const int rr = is_a ? r : r - BM, sub = rr / EPR, k = rr - sub * EPR;
             const int lc = (lane & 7) ^ tn_swz<CT>(k);                  // logical chunk this lane fetches
             const size_t ld_b = is_a ? lda_b : ldb_b;
-            src[c] = (is_a ? Ag : Bg) + (size_t)k * ld_b + (size_t)sub * kTileBytesK + lc * 16;
             kadv[c] = (size_t)EPR * ld_b;
+            src[c] = (is_a ? Ag : Bg) + (size_t)k * ld_b + (size_t)sub * kTileBytesK + lc * 16 + (size_t)k_first * kadv[c];
         } else {
             const int lc = (lane & 7) ^ ((r >> 1) & 7);                 // logical chunk this lane fetches
             src[c] = (r < BM ? Ag + (size_t)r * lda_b : Bg + (size_t)(r - BM) * ldb_b) + lc * 16;
@@ -640,7 +648,8 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     const int M = w.M, N = w.N;
     constexpr int QC = BN / 4;
     if constexpr (TN) {      // the weight gradients are the only K-major products
-        tile_pass<float, float, false, false, BM, BN, NT>(Cs, reinterpret_cast<float*>(w.out0), w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
+        float* G = w.ksplit > 1 ? reinterpret_cast<float*>(w.out1) + (size_t)ks * M * w.ld0 : reinterpret_cast<float*>(w.out0);
+        tile_pass<float, float, false, false, BM, BN, NT>(Cs, G, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
             [](float c, float, bool) { return c; });
     } else
     switch (w.kind) {
@@ -1142,6 +1151,30 @@ void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStre
     if (n_blocks <= 0) return;
     if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_col2im<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
     else AVAE_LAUNCH((k_col2im<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+}
+
+// ------------------------------------------------------------------ split-K reduction
+__global__ void __launch_bounds__(kThreads) k_reduce(ReduceArgs a) {
+    const int bid = blockIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
+    const ReduceSeg& g = a.seg[it];
+    const int i = ((bid - g.block_base) * kThreads + (int)threadIdx.x) * 4;       // n and stride are multiples of 4
+    if (i >= g.n) return;
+    float acc[4];
+    load4<float>(g.src + i, acc);
+    for (int s = 1; s < g.parts; ++s) {
+        float v[4];
+        load4<float>(g.src + (size_t)s * g.stride + i, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    store4<float>(g.dst + i, acc);
+}
+
+void launch_reduce(const ReduceArgs& a, int n_blocks, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    AVAE_LAUNCH(k_reduce, dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
 // ------------------------------------------------------------------ strided fill (constant-1 columns)
