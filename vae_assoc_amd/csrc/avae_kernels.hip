@@ -1059,26 +1059,42 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
     const int M = g.B * g.OH * g.OW, K = g.k * g.k * g.Cin, KC = K + (g.ones ? 1 : 0);
     const CT* src = reinterpret_cast<const CT*>(w.src);
     const int c4 = (tid & 15) * 4;
+    const int kc = c0 + c4;
+    // The thread's 4 consecutive patch columns: with Cin % 4 == 0 they are 4 channels of ONE filter position (kh, kw), so the
+    // position is decoded once per thread (not per element and row) and the 4 channels are one vector load; the dilation d is 1 or 2
+    // (mask / shift instead of % and /).  The scalar path below keeps single-channel inputs (first conv stage) and odd shapes.
+    const bool quad = (g.Cin & 3) == 0 && (g.d == 1 || g.d == 2) && kc < K;
+    const int kpos = quad ? kc / g.Cin : 0, ci0 = quad ? kc - kpos * g.Cin : 0, kh0 = kpos / g.k, kw0 = kpos - kh0 * g.k;
+    const int dmask = g.d - 1, dshift = g.d >> 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (tid >> 4) + 16 * i;
-        const int m = r0 + r, kc = c0 + c4;
+        const int m = r0 + r;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (m < M && kc < KC) {
             const int b = m / (g.OH * g.OW), rem = m - b * g.OH * g.OW, oh = rem / g.OW, ow = rem - oh * g.OW;
+            if (quad) {
+                const int nh = oh * g.so + kh0 - g.pad, nw = ow * g.so + kw0 - g.pad;
+                if (nh >= 0 && nw >= 0 && !(nh & dmask) && !(nw & dmask)) {
+                    const int ih = nh >> dshift, iw = nw >> dshift;
+                    if (ih < g.IH && iw < g.IW)
+                        load4<CT>(src + (size_t)b * g.src_sb + (size_t)(ih * g.IW + iw) * g.src_sp + ci0, v);
+                }
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kidx = kc + e;
-                if (kidx < K) {
-                    const int kpos = kidx / g.Cin, ci = kidx - kpos * g.Cin, kh = kpos / g.k, kw = kpos - kh * g.k;
-                    const int nh = oh * g.so + kh - g.pad, nw = ow * g.so + kw - g.pad;
-                    if (nh >= 0 && nw >= 0 && nh % g.d == 0 && nw % g.d == 0) {
-                        const int ih = nh / g.d, iw = nw / g.d;
-                        if (ih < g.IH && iw < g.IW)
-                            v[e] = ct_load<CT>(src + (size_t)b * g.src_sb + (size_t)(ih * g.IW + iw) * g.src_sp + ci);
+                for (int e = 0; e < 4; ++e) {
+                    const int kidx = kc + e;
+                    if (kidx < K) {
+                        const int kp = kidx / g.Cin, ci = kidx - kp * g.Cin, kh = kp / g.k, kw = kp - kh * g.k;
+                        const int nh = oh * g.so + kh - g.pad, nw = ow * g.so + kw - g.pad;
+                        if (nh >= 0 && nw >= 0 && nh % g.d == 0 && nw % g.d == 0) {
+                            const int ih = nh / g.d, iw = nw / g.d;
+                            if (ih < g.IH && iw < g.IW)
+                                v[e] = ct_load<CT>(src + (size_t)b * g.src_sb + (size_t)(ih * g.IW + iw) * g.src_sp + ci);
+                        }
+                    } else if (kidx == K && g.ones) {
+                        v[e] = 1.0f;
                     }
-                } else if (kidx == K && g.ones) {
-                    v[e] = 1.0f;
                 }
             }
             store_row<CT>(reinterpret_cast<CT*>(w.P) + (size_t)m * w.ldp + kc, v, KC - kc);
@@ -1086,8 +1102,6 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
     }
 }
 
-// Gradient of a conv-like layer's input from its fp32 patch gradients: every input element sums the
-// patch entries that were gathered from it (no atomics), then the producing layer's act' is applied.
 template <typename CT>
 __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
     const int bid = blockIdx.x, tid = threadIdx.x;
@@ -1109,6 +1123,44 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (pix < R && cc < C) {
             const int b = pix / (g.IH * g.IW), rem = pix - b * g.IH * g.IW, ih = rem / g.IW, iw = rem - ih * g.IW;
+            // Fast path: the thread's 4 columns are 4 channels of one pixel (not straddling the mu | lv halves of the latent
+            // mode), so the k x k walk over the patch gradients is done ONCE for all four with one 16-byte load per position; the
+            // output stride so is 1 or 2 (mask / shift instead of % and /).  Each dP element is read exactly once overall.
+            const bool quad = (g.Cin & 3) == 0 && (g.so == 1 || g.so == 2) && cc + 3 < C && (!latent || (w.nz & 3) == 0);
+            if (quad) {
+                const int ci0 = latent ? (cc < w.nz ? cc : cc - w.nz) : cc;
+                const int smask = g.so - 1, sshift = g.so >> 1;
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int kh = 0; kh < g.k; ++kh) {
+                    const int nh = ih * g.d + g.pad - kh;
+                    if (nh < 0 || (nh & smask)) continue;
+                    const int oh = nh >> sshift;
+                    if (oh >= g.OH) continue;
+                    for (int kw = 0; kw < g.k; ++kw) {
+                        const int nw = iw * g.d + g.pad - kw;
+                        if (nw < 0 || (nw & smask)) continue;
+                        const int ow = nw >> sshift;
+                        if (ow >= g.OW) continue;
+                        float t[4];
+                        load4<float>(w.dP + (size_t)((b * g.OH + oh) * g.OW + ow) * w.lddp + (kh * g.k + kw) * g.Cin + ci0, t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] += t[e];
+                    }
+                }
+                if (latent) {        // dmu = dz + g0mu ; dlv = dz * F + g0lv   (g0 = [g0mu | g0lv | F], reparameterisation)
+                    const int lde = (w.nz + 3) & ~3;
+                    const float* gr = w.g0 + (size_t)pix * 3 * lde;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = cc < w.nz ? acc[e] + gr[ci0 + e] : acc[e] * gr[2 * lde + ci0 + e] + gr[lde + ci0 + e];
+                } else if (w.yprev) {
+                    float y[4];
+                    load4<CT>(reinterpret_cast<const CT*>(w.yprev) + (size_t)pix * w.ldy + ci0, y);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] *= act_bwd(w.act, y[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[e];
+            } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int col = cc + e;
@@ -1136,6 +1188,7 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
                     acc *= act_bwd(w.act, ct_load<CT>(reinterpret_cast<const CT*>(w.yprev) + (size_t)pix * w.ldy + ci));
                 }
                 v[e] = acc;
+            }
             }
             store_row<CT>(reinterpret_cast<CT*>(w.dA) + (size_t)pix * w.lda + cc, v, C - cc);
         }
