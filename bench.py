@@ -115,7 +115,7 @@ def launch_work(archs, B, es):
             add(name, (B * o + i * o + 2 * B * i) * es, 2 * B * i * o)
 
         def wgrad(i, o):                                                         # X, dA in (+ optimiser traffic below)
-            wg.append(((B * i + B * o) * es, 2 * B * (i + 1) * o, (i + 1) * o))
+            wg.append(((B * i + B * o) * es, 2 * B * (i + 1) * o, (i + 1) * o, o))
         dgrad("bwd_out", *outl)
         for k in range(L - 1, 0, -1):
             dgrad("bwd_dec%d" % (k + 1), *dec[k])
@@ -133,10 +133,15 @@ def launch_work(archs, B, es):
         wgrad(*enc[0])
         add("prep", B * n_in * (4 + 4 + es), 0)
         P += sum((i + 1) * o for i, o in enc + dec + [head, outl])
-    chunk = 12                                                                   # kMaxItemsPerLaunch
-    for c0 in range(0, len(wg), chunk):
-        suffix = str(c0 // chunk + 1) if len(wg) > chunk else ""
-        for by, fl, p in wg[c0:c0 + chunk]:
+    # the host's launch chunking (build_training_plan): big nets keep their narrow products in launches of their own
+    narrow = lambda it: it[2] // it[3] <= 64 or it[3] <= 64                       # M = in+1, N = out
+    wide128 = sum(-(-(it[2] // it[3]) // 128) * -(-it[3] // 128) for it in wg if not narrow(it))
+    groups = [[it for it in wg if not narrow(it)], [it for it in wg if narrow(it)]] if wide128 >= 192 else [wg]
+    chunk = 32                                                                   # kMaxTnItems
+    chunks = [g[c0:c0 + chunk] for g in groups for c0 in range(0, len(g), chunk)]
+    for c, items in enumerate(chunks):
+        suffix = str(c + 1) if len(chunks) > 1 else ""
+        for by, fl, p, _ in items:
             add("wgrad" + suffix, by + p * 4, fl)                                # fp32 gradient out
     add("adam", 7 * P * 4 + P * es, 0)
     return out, P

@@ -214,6 +214,8 @@ def test_config_c5_three_modalities_lambda_sweep(V, lam):
          binary=[True, False], w=[1.0, 1.0], lam=0.05, act="relu", B=200),          # n_z=64: 128x128 head tile
     dict(archs=[make_arch("a", 40, 24, 24, 6), make_arch("b", 30, 24, 24, 6), make_arch("c", 20, 16, 16, 6), make_arch("d", 10, 8, 8, 6)],
          binary=[True, False, True, False], w=[1.0, 2.0, 3.0, 4.0], lam=0.3, act="identity", B=33),
+    dict(archs=[make_arch("a", 128, 0, 0, 16, n_hidden=[64, 128]), make_arch("b", 64, 0, 0, 16, n_hidden=[192])],
+         binary=[True, False], w=[1.0, 1.0], lam=0.2, act="softplus", B=96),        # fan-ins of k*64: bias gradient from the ones MFMA
 ])
 def test_shapes_and_options(V, case, dtype):
     check_step_parity(V, case["archs"], case["binary"], case["w"], case["lam"], case["act"], case["B"], dtype)

@@ -42,6 +42,9 @@ struct WorkItem {
     int binary;
     int ksplit, kchunk;      // K_WGRAD with a long K (conv stages: K = batch x output pixels): the K range is cut into ksplit
                              // chunks of kchunk K tiles, chunk s writing its own fp32 slice out1 + s*M*ld0 (summed by k_reduce)
+    int bias_row;            // K_WGRAD, > 0: the tiles cover rows [0, M) = the weight rows only and the bias gradient (row
+                             // bias_row = M, the column sums of dA) comes from one extra MFMA per fragment with an all-ones A
+                             // operand in the first tile row -- set by the host when M+1 rows would cost a whole tile row more
     int slot_base;           // first cost-partial slot written by this item
     int n_slots;             // K_COST: number of partial slots to sum
     int n_mod;               // K_LATENT
@@ -77,6 +80,28 @@ struct LaunchArgs {
     int grid_x;
     int pad[2];
     WorkItem items[kMaxItemsPerLaunch];
+};
+
+// The weight-gradient launches (K-major operands, K_WGRAD only) carry a compact item: 72 bytes instead of 184, so every
+// weight gradient of a step fits ONE launch's kernel-argument segment (4 KiB) and the tiles of all layers share the CUs'
+// rounds (C4: 800 tiles in 4 rounds of one launch instead of 2 + 2 rounds of two).
+struct TnItem {
+    const void* A;           // X_aug   [K = batch rows][lda]
+    const void* B;           // dA      [K][ldb]
+    float* out;              // fp32 gradient [M][ld0]; split-K: slice s at out + s*M*ld0
+    int M, N, K;
+    int lda, ldb, ld0;
+    int tiles_m, tiles_n;
+    int ksplit, kchunk;
+    int bias_row, pad;       // see WorkItem::bias_row
+};
+constexpr int kMaxTnItems = 32;
+struct TnLaunchArgs {
+    int n_items;
+    int grid_x;
+    int xcd_group;           // G = 1, 2, 4 or 8 items share the 8 XCDs: each item's tiles run on 8/G of them (see k_grouped)
+    int pad;
+    TnItem items[kMaxTnItems];
 };
 
 struct DevState {
@@ -188,8 +213,10 @@ constexpr int kStampLaunches = 32, kStampBlocks = 1024, kStampWords = 8;
 
 // launchers implemented in avae_kernels.hip
 int tile_lds_bytes(int tile_cfg, bool two_c_tiles);
-void launch_grouped(int compute_dtype, int tile_cfg, bool tn, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
+void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
                     DevState* st, hipStream_t s, unsigned long long* stamps = nullptr, int launch_id = 0);
+void launch_grouped_tn(int compute_dtype, int tile_cfg, const TnLaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
+                       DevState* st, hipStream_t s, unsigned long long* stamps = nullptr, int launch_id = 0);
 void launch_adam(int compute_dtype, const AdamArgs& a, int n_blocks, hipStream_t s);
 void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s);
 const void* prep_kernel(int compute_dtype);          // for hipGraphExecKernelNodeSetParams on the captured staging node

@@ -96,6 +96,7 @@ struct Launch {
     int grid_x = 1, grid_y = 1;   // grouped kernel: tile slot x item
     bool tn = false;              // K-major operands (the weight-gradient launches)
     LaunchArgs args{};
+    TnLaunchArgs targs{};         // tn launches carry compact items instead
     GatherArgs ga{};
     Col2imArgs ca{};
     ReduceArgs ra{};
@@ -588,7 +589,9 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
     for (int i = first; i < first + count; ++i) {
         WorkItem& w = items[i];
         if (is_gemm(w.kind)) {
-            w.tiles_m = (w.M + TM - 1) / TM;
+            w.bias_row = 0;
+            if (w.kind == K_WGRAD && w.M > 1 && (w.M - 1) % TM == 0 && !std::getenv("AVAE_NO_BIAS_MFMA")) w.bias_row = w.M - 1;
+            w.tiles_m = (w.M - (w.bias_row > 0 ? 1 : 0) + TM - 1) / TM;
             w.tiles_n = (w.N + T - 1) / T;
             if ((w.kind == K_FWD_HEAD || w.kind == K_DGRAD_LATENT) && w.tiles_n != 1) throw Err("internal error: head tile");
             if (w.kind == K_FWD_OUT_LOSS) { w.slot_base = *next_slot; *next_slot += w.tiles_m * w.tiles_n; }
@@ -609,11 +612,36 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         for (int i = first; i < first + count; ++i) two = two || items[i].kind == K_FWD_HEAD || items[i].kind == K_DGRAD_LATENT;
         L.lds = tile_lds_bytes(L.cfg, two);
     }
-    if (count > kMaxItemsPerLaunch) throw Err("internal error: too many items in one launch");
+    L.tn = true;
+    for (int i = first; i < first + count; ++i) L.tn = L.tn && items[i].kind == K_WGRAD;
+    if (count > (L.tn ? kMaxTnItems : kMaxItemsPerLaunch)) throw Err("internal error: too many items in one launch");
     std::memset(&L.args, 0, sizeof(L.args));
-    L.args.n_items = count;
-    L.args.grid_x = L.grid_x;
-    for (int i = 0; i < count; ++i) L.args.items[i] = items[first + i];
+    std::memset(&L.targs, 0, sizeof(L.targs));
+    if (L.tn) {
+        L.targs.n_items = count;
+        L.targs.grid_x = L.grid_x;
+        // big weight gradients: concentrate each item on 8/G XCDs (the launch is bound by L2 misses); G must leave no XCD
+        // without an item, so it divides the item count
+        int G = 1;
+        if (L.cfg == 2) for (int g : {4, 2}) if (count % g == 0) { G = g; break; }
+        if (const char* e = std::getenv("AVAE_TN_G")) G = std::atoi(e);
+        if (G != 1 && G != 2 && G != 4 && G != 8) throw Err("AVAE_TN_G must be 1, 2, 4 or 8");
+        L.targs.xcd_group = G;
+        L.grid_y = (count + G - 1) / G * G;
+        L.blocks = L.grid_x * L.grid_y;
+        for (int i = 0; i < count; ++i) {
+            const WorkItem& w = items[first + i];
+            TnItem& t = L.targs.items[i];
+            t.A = w.A; t.B = w.B; t.out = reinterpret_cast<float*>(w.ksplit > 1 ? w.out1 : w.out0);
+            t.bias_row = w.bias_row;
+            t.M = w.bias_row > 0 ? w.M - 1 : w.M; t.N = w.N; t.K = w.K; t.lda = w.lda; t.ldb = w.ldb; t.ld0 = w.ld0;
+            t.tiles_m = w.tiles_m; t.tiles_n = w.tiles_n; t.ksplit = w.ksplit; t.kchunk = w.kchunk;
+        }
+    } else {
+        L.args.n_items = count;
+        L.args.grid_x = L.grid_x;
+        for (int i = 0; i < count; ++i) L.args.items[i] = items[first + i];
+    }
     if (*next_slot > h->n_partial) throw Err("internal error: cost partial slots overflow");
     return L;
 }
@@ -766,8 +794,8 @@ void build_training_plan(avae_handle* h) {
         for (const WorkItem& w : wg) if (!is_narrow(w)) wide128 += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
         std::vector<std::vector<WorkItem>> chunks;
         auto chunk_up = [&](const std::vector<WorkItem>& v) {
-            for (size_t i0 = 0; i0 < v.size(); i0 += kMaxItemsPerLaunch)
-                chunks.emplace_back(v.begin() + i0, v.begin() + std::min(v.size(), i0 + kMaxItemsPerLaunch));
+            for (size_t i0 = 0; i0 < v.size(); i0 += kMaxTnItems)
+                chunks.emplace_back(v.begin() + i0, v.begin() + std::min(v.size(), i0 + (size_t)kMaxTnItems));
         };
         if (wide128 >= 192) {
             std::vector<WorkItem> wide, narrow;
@@ -779,7 +807,6 @@ void build_training_plan(avae_handle* h) {
         for (size_t c = 0; c < chunks.size(); ++c) {
             group("wgrad" + (chunks.size() > 1 ? std::to_string(c + 1) : std::string()), h->wgrad,
                   [&] { for (const WorkItem& w : chunks[c]) h->items.push_back(w); });
-            h->wgrad.back().tn = true;
         }
         {   // the split-K slices of the conv stages' weight gradients -> the gradient buffer, in fixed order
             Launch R;
@@ -913,7 +940,8 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         if (L.type == 1) launch_gather(h->cfg.compute_dtype, L.ga, L.blocks, s);
         else if (L.type == 2) launch_col2im(h->cfg.compute_dtype, L.ca, L.blocks, s);
         else if (L.type == 3) launch_reduce(L.ra, L.blocks, s);
-        else launch_grouped(h->cfg.compute_dtype, L.cfg, L.tn, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
+        else if (L.tn) launch_grouped_tn(h->cfg.compute_dtype, L.cfg, L.targs, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
+        else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to
             std::fprintf(stderr, "[avae] launch %s type=%d cfg=%d items=%d blocks=%d\n", L.name.c_str(), L.type, L.cfg, L.count, L.blocks);
             for (int i = 0; i < L.args.n_items && L.type == 0; ++i)
@@ -1013,6 +1041,7 @@ Launch relocated(const avae_handle* h, const Launch& L0, int j) {
         WorkItem& w = L.args.items[i];
         fix(w.A); fix(w.B); fix(w.out0); fix(w.out1); fix(w.out2); fix(w.aux0); fix(w.aux1); fix(w.aux2); fix(w.eps);
     }
+    for (int i = 0; i < L.targs.n_items && L.type == 0; ++i) { TnItem& t = L.targs.items[i]; fix(t.A); fix(t.B); fix(t.out); }
     for (int i = 0; i < L.ga.n_seg && L.type == 1; ++i) fix(L.ga.seg[i].src);
     return L;
 }

@@ -412,8 +412,22 @@ int tile_lds_bytes(int tile_cfg, bool two_c_tiles) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char avae_dyn_smem[];
 
+template <bool TN> struct ArgsOf { typedef LaunchArgs type; };
+template <> struct ArgsOf<true> { typedef TnLaunchArgs type; };
+
+__device__ __forceinline__ WorkItem item_of(const LaunchArgs& args, int y) { return args.items[y]; }
+__device__ __forceinline__ WorkItem item_of(const TnLaunchArgs& args, int y) {
+    const TnItem ti = args.items[y];
+    WorkItem w = {};
+    w.kind = K_WGRAD;
+    w.M = ti.M; w.N = ti.N; w.K = ti.K; w.lda = ti.lda; w.ldb = ti.ldb; w.ld0 = ti.ld0;
+    w.tiles_m = ti.tiles_m; w.tiles_n = ti.tiles_n; w.ksplit = ti.ksplit; w.kchunk = ti.kchunk; w.bias_row = ti.bias_row;
+    w.A = ti.A; w.B = ti.B; w.out0 = ti.out; w.out1 = ti.out;
+    return w;
+}
+
 template <typename CT, int BM, int BN, int RING, int NW = 4, bool TN = false>
-__global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const LaunchArgs args, DevState* st, int lds_bytes,
+__global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const typename ArgsOf<TN>::type args, DevState* st, int lds_bytes,
                                                       unsigned long long* stamps, int launch_id) {
     unsigned char* smem = avae_dyn_smem;
     float* red = reinterpret_cast<float*>(smem + lds_bytes - 64);
@@ -440,22 +454,36 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
 #define AVAE_LGKM0()
 #endif
 
-    const WorkItem w = args.items[blockIdx.y];                    // one burst of scalar loads from the kernarg segment
+    // Which item, and which of its S contiguous tile-list chunks, this workgroup serves.  Hardware deals workgroups
+    // round-robin over the 8 XCDs (private 4 MiB L2 each) in linear order y*grid_x + x, and grid_x is a multiple of 8, so
+    // x%8 names the XCD.  Default (G = 1, S = 8): item y is spread over all 8 XCDs, XCD c taking chunk c of its tile list
+    // (tiles that share A row panels / B column panels meet in one L2; heavy and light items stay balanced).
+    // Big weight gradients (G > 1): the G items y0..y0+G-1 share the 8 XCDs instead, item y0+i owning XCDs [i*S, (i+1)*S)
+    // with S = 8/G -- the 32 tiles resident on an XCD then come from one or two items rather than eight, and stream
+    // a third to a half of the operand panels through its L2 (C4: the launch is bound by L2 misses, not by tile count).
+    int item_y = blockIdx.y, part = blockIdx.x & 7, idx = blockIdx.x >> 3, S = 8;
+    if constexpr (TN) {
+        const int G = args.xcd_group;
+        if (G > 1) {
+            S = 8 / G;
+            item_y = (blockIdx.y / G) * G + part / S;
+            idx += (blockIdx.y % G) * (gridDim.x >> 3);
+            part = part % S;
+            if (item_y >= args.n_items) return;                       // last group of a launch whose item count G does not divide
+        }
+    }
+    const WorkItem w = item_of(args, item_y);                     // one burst of scalar loads from the kernarg segment
     // ... and it has to BE one burst: left alone, the compiler fetches the few fields the tile-index branch below needs,
     // waits, and only then fetches the operand pointers -- two kernel-argument round trips (~0.25 us each) before the
     // first load of every workgroup.  Naming the fields here puts all their s_loads ahead of the first wait.
-    asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.aux0), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.ldx), "s"(lds_bytes));
-    // XCD-aware tile order inside the item: hardware deals workgroups round-robin over the 8 XCDs
-    // (private 4 MiB L2 each) in linear order y*grid_x + x, and grid_x is a multiple of 8, so x%8 names the XCD group.
-    // Each group gets one contiguous chunk of the item's tile list (tiles that share A row panels /
-    // B column panels meet in one L2); every item is still spread over all XCDs, which keeps heavy
-    // and light items balanced.  Bijective for any tile count; only speed depends on it.
-    int t;
+    if constexpr (TN) asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.kchunk), "s"(lds_bytes));
+    else asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.aux0), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.ldx), "s"(lds_bytes));
+    int t;                       // bijective for any tile count; only speed depends on the order
     {
-        const int local = blockIdx.x, nt = w.tiles_m * w.tiles_n * (TN && w.ksplit > 1 ? w.ksplit : 1);
-        const int q = nt >> 3, r = nt & 7, xcd = local & 7, j = local >> 3;
-        if (j >= q + (xcd < r ? 1 : 0)) return;                   // padding block behind the item's last tile
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int nt = w.tiles_m * w.tiles_n * (TN && w.ksplit > 1 ? w.ksplit : 1);
+        const int q = nt / S, r = nt - q * S;
+        if (idx >= q + (part < r ? 1 : 0)) return;                // padding block behind the chunk's last tile
+        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx;
     }
     int ks = 0;                  // split-K chunk of this workgroup (weight gradients with a long K only)
     if constexpr (TN) {
@@ -536,6 +564,16 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
 #pragma unroll
     for (int j = 0; j < NI; ++j) offB[j] = TN ? BM * kTileBytesK + tn_frag_off<CT>(wc * WN + j * 16, lane) : 0;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // weight gradients whose bias row would need a tile row of its own (in = k * BM): the first tile row's top waves add
+    // it from the B fragments they hold anyway -- one MFMA per fragment against an all-ones A operand (every row of the
+    // 16x16 result is the column sum) instead of a fifth row of tiles that multiplies 255 rows of padding.
+    f32x4 accb[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool do_bias = false;
+    if constexpr (TN) do_bias = w.bias_row > 0 && tm == 0 && (wave_u >> 1) == 0;
+    const unsigned one_bits = sizeof(CT) == 2 ? 0x3F803F80u : 0x3F800000u;
+    const u32x4 ones = {one_bits, one_bits, one_bits, one_bits};
 
 #define AVAE_DMA(kt, buf)                                                                              \
     {                                                                                                  \
@@ -581,6 +619,9 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
             _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a0[i], b0[j], acc[i][j]);           \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
             _Pragma("unroll") for (int j = 0; j < NI; ++j) mma<CT>(a1[i], b1[j], acc[i][j]);           \
+        if constexpr (TN) if (do_bias) {                                                               \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j) { mma<CT>(ones, b0[j], accb[j]); mma<CT>(ones, b1[j], accb[j]); } \
+        }                                                                                              \
         if ((do_dma) && dma_late) AVAE_ABL_DMA(dma_kt, dma_buf)                                        \
         AVAE_MFMA_DRAIN()                                                                              \
         AVAE_LT(5)                                                                                     \
@@ -648,9 +689,17 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     const int M = w.M, N = w.N;
     constexpr int QC = BN / 4;
     if constexpr (TN) {      // the weight gradients are the only K-major products
-        float* G = w.ksplit > 1 ? reinterpret_cast<float*>(w.out1) + (size_t)ks * M * w.ld0 : reinterpret_cast<float*>(w.out0);
+        const int rows = M + (w.bias_row > 0 ? 1 : 0);
+        float* G = w.ksplit > 1 ? reinterpret_cast<float*>(w.out1) + (size_t)ks * rows * w.ld0 : reinterpret_cast<float*>(w.out0);
         tile_pass<float, float, false, false, BM, BN, NT>(Cs, G, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
             [](float c, float, bool) { return c; });
+        if (do_bias && lane < 16) {               // C row 0 of the ones product: lanes 0-15, register 0
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = n0 + wc * WN + j * 16 + lane;
+                if (col < N) G[(size_t)w.bias_row * w.ld0 + col] = accb[j][0];
+            }
+        }
     } else
     switch (w.kind) {
     case K_FWD_HIDDEN: {
@@ -838,8 +887,7 @@ template <typename K> static void set_max_lds(K kernel) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-void launch_grouped(int compute_dtype, int tile_cfg, bool tn, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
-                    DevState* st, hipStream_t s, unsigned long long* stamps, int launch_id) {
+static void grouped_attrs_once() {
     static const bool once = [] {
         set_max_lds(k_grouped<__bf16, 64, 64, 4>); set_max_lds(k_grouped<__bf16, 128, 128, 2>); set_max_lds(k_grouped<__bf16, 256, 128, 3, 8>);
         set_max_lds(k_grouped<float, 64, 64, 4>); set_max_lds(k_grouped<float, 128, 128, 2>); set_max_lds(k_grouped<float, 256, 128, 3, 8>);
@@ -851,26 +899,41 @@ void launch_grouped(int compute_dtype, int tile_cfg, bool tn, const LaunchArgs& 
         return true;
     }();
     (void)once;
-    dim3 grid(grid_x, grid_y), block(tile_cfg == 2 ? 512 : kThreads);
+}
+
 #define AVAE_GO(CT, TNF)                                                                                                     \
     do {                                                                                                                     \
         if (tile_cfg == 0) AVAE_LAUNCH((k_grouped<CT, 64, 64, 4, 4, TNF>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);        \
         else if (tile_cfg == 2) AVAE_LAUNCH((k_grouped<CT, 256, 128, 3, 8, TNF>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id); \
         else AVAE_LAUNCH((k_grouped<CT, 128, 128, 2, 4, TNF>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);                    \
     } while (0)
-    if (tile_cfg == 3) {      // NT only
+
+void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
+                    DevState* st, hipStream_t s, unsigned long long* stamps, int launch_id) {
+    grouped_attrs_once();
+    dim3 grid(grid_x, grid_y), block(tile_cfg == 2 ? 512 : kThreads);
+    if (tile_cfg == 3) {
         if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_grouped<__bf16, 32, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
         else AVAE_LAUNCH((k_grouped<float, 32, 64, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-    } else if (tile_cfg == 5) {      // NT only
+    } else if (tile_cfg == 5) {
         if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_grouped<__bf16, 32, 32, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
         else AVAE_LAUNCH((k_grouped<float, 32, 32, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-    } else if (tile_cfg == 4) {      // NT only
+    } else if (tile_cfg == 4) {
         if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_grouped<__bf16, 64, 128, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
         else AVAE_LAUNCH((k_grouped<float, 64, 128, 4>), grid, block, lds_bytes, s, args, st, lds_bytes, stamps, launch_id);
-    } else if (compute_dtype == AVAE_BF16) { if (tn) AVAE_GO(__bf16, true); else AVAE_GO(__bf16, false); }
-    else { if (tn) AVAE_GO(float, true); else AVAE_GO(float, false); }
-#undef AVAE_GO
+    } else if (compute_dtype == AVAE_BF16) AVAE_GO(__bf16, false);
+    else AVAE_GO(float, false);
 }
+
+// The weight-gradient launches: K-major operands, compact items (tile shapes 0, 1, 2 only).
+void launch_grouped_tn(int compute_dtype, int tile_cfg, const TnLaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
+                       DevState* st, hipStream_t s, unsigned long long* stamps, int launch_id) {
+    grouped_attrs_once();
+    dim3 grid(grid_x, grid_y), block(tile_cfg == 2 ? 512 : kThreads);
+    if (compute_dtype == AVAE_BF16) AVAE_GO(__bf16, true);
+    else AVAE_GO(float, true);
+}
+#undef AVAE_GO
 
 // ------------------------------------------------------------------ Adam + shadow refresh
 // TF-1 AdamOptimizer dense update (reference vae_assoc.py:373-374; TF training_ops ApplyAdam):
