@@ -45,6 +45,7 @@ struct WorkItem {
     int bias_row;            // K_WGRAD, > 0: the tiles cover rows [0, M) = the weight rows only and the bias gradient (row
                              // bias_row = M, the column sums of dA) comes from one extra MFMA per fragment with an all-ones A
                              // operand in the first tile row -- set by the host when M+1 rows would cost a whole tile row more
+    int tile_off, tile_cnt;  // K_WGRAD launches only (TnItem)
     int slot_base;           // first cost-partial slot written by this item
     int n_slots;             // K_COST: number of partial slots to sum
     int n_mod;               // K_LATENT
@@ -82,7 +83,7 @@ struct LaunchArgs {
     WorkItem items[kMaxItemsPerLaunch];
 };
 
-// The weight-gradient launches (K-major operands, K_WGRAD only) carry a compact item: 72 bytes instead of 184, so every
+// The weight-gradient launches (K-major operands, K_WGRAD only) carry a compact item: 80 bytes instead of 192, so every
 // weight gradient of a step fits ONE launch's kernel-argument segment (4 KiB) and the tiles of all layers share the CUs'
 // rounds (C4: 800 tiles in 4 rounds of one launch instead of 2 + 2 rounds of two).
 struct TnItem {
@@ -93,7 +94,9 @@ struct TnItem {
     int lda, ldb, ld0;
     int tiles_m, tiles_n;
     int ksplit, kchunk;
-    int bias_row, pad;       // see WorkItem::bias_row
+    int bias_row;            // see WorkItem::bias_row
+    int tile_off, tile_cnt;  // this entry covers tiles [tile_off, tile_off + tile_cnt) of the item's tile list: the host cuts
+    int pad;                 // items with many tiles into several entries so that the grid (x = longest entry) is not mostly padding
 };
 constexpr int kMaxTnItems = 32;
 struct TnLaunchArgs {

@@ -618,25 +618,46 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
     std::memset(&L.args, 0, sizeof(L.args));
     std::memset(&L.targs, 0, sizeof(L.targs));
     if (L.tn) {
-        L.targs.n_items = count;
-        L.targs.grid_x = L.grid_x;
         // big weight gradients: concentrate each item on 8/G XCDs (the launch is bound by L2 misses); G must leave no XCD
         // without an item, so it divides the item count
         int G = 1;
         if (L.cfg == 2) for (int g : {4, 2}) if (count % g == 0) { G = g; break; }
         if (const char* e = std::getenv("AVAE_TN_G")) G = std::atoi(e);
         if (G != 1 && G != 2 && G != 4 && G != 8) throw Err("AVAE_TN_G must be 1, 2, 4 or 8");
-        L.targs.xcd_group = G;
-        L.grid_y = (count + G - 1) / G * G;
-        L.blocks = L.grid_x * L.grid_y;
+        auto tiles_of = [&](const WorkItem& w) { return w.tiles_m * w.tiles_n * (w.ksplit > 1 ? w.ksplit : 1); };
+        // The grid is (longest entry) x (entries), so layers of very different size would make it mostly padding
+        // workgroups (C2: 1248 workgroups for 416 tiles).  Items are therefore cut into entries of at most SX tiles, SX
+        // chosen to launch the fewest workgroups within the entry table's size.
+        int SX = L.grid_x;
+        if (G == 1 && !std::getenv("AVAE_NO_TN_SLICES")) {
+            long best = -1;
+            for (int sx = 8; sx <= L.grid_x; sx += 8) {
+                long entries = 0;
+                for (int i = first; i < first + count; ++i) entries += (tiles_of(items[i]) + sx - 1) / sx;
+                if (entries > kMaxTnItems) continue;
+                if (best < 0 || entries * sx <= best) { best = entries * sx; SX = sx; }
+            }
+        }
+        int n = 0;
         for (int i = 0; i < count; ++i) {
             const WorkItem& w = items[first + i];
-            TnItem& t = L.targs.items[i];
-            t.A = w.A; t.B = w.B; t.out = reinterpret_cast<float*>(w.ksplit > 1 ? w.out1 : w.out0);
-            t.bias_row = w.bias_row;
-            t.M = w.bias_row > 0 ? w.M - 1 : w.M; t.N = w.N; t.K = w.K; t.lda = w.lda; t.ldb = w.ldb; t.ld0 = w.ld0;
-            t.tiles_m = w.tiles_m; t.tiles_n = w.tiles_n; t.ksplit = w.ksplit; t.kchunk = w.kchunk;
+            const int nt = tiles_of(w);
+            for (int off = 0; off < nt; off += SX) {
+                if (n >= kMaxTnItems) throw Err("internal error: too many weight-gradient entries");
+                TnItem& t = L.targs.items[n++];
+                t.A = w.A; t.B = w.B; t.out = reinterpret_cast<float*>(w.ksplit > 1 ? w.out1 : w.out0);
+                t.bias_row = w.bias_row;
+                t.M = w.bias_row > 0 ? w.M - 1 : w.M; t.N = w.N; t.K = w.K; t.lda = w.lda; t.ldb = w.ldb; t.ld0 = w.ld0;
+                t.tiles_m = w.tiles_m; t.tiles_n = w.tiles_n; t.ksplit = w.ksplit; t.kchunk = w.kchunk;
+                t.tile_off = off; t.tile_cnt = std::min(SX, nt - off);
+            }
         }
+        L.grid_x = SX;
+        L.targs.n_items = n;
+        L.targs.grid_x = L.grid_x;
+        L.targs.xcd_group = G;
+        L.grid_y = (n + G - 1) / G * G;
+        L.blocks = L.grid_x * L.grid_y;
     } else {
         L.args.n_items = count;
         L.args.grid_x = L.grid_x;

@@ -422,6 +422,7 @@ __device__ __forceinline__ WorkItem item_of(const TnLaunchArgs& args, int y) {
     w.kind = K_WGRAD;
     w.M = ti.M; w.N = ti.N; w.K = ti.K; w.lda = ti.lda; w.ldb = ti.ldb; w.ld0 = ti.ld0;
     w.tiles_m = ti.tiles_m; w.tiles_n = ti.tiles_n; w.ksplit = ti.ksplit; w.kchunk = ti.kchunk; w.bias_row = ti.bias_row;
+    w.tile_off = ti.tile_off; w.tile_cnt = ti.tile_cnt;
     w.A = ti.A; w.B = ti.B; w.out0 = ti.out; w.out1 = ti.out;
     return w;
 }
@@ -480,10 +481,10 @@ __global__ void __launch_bounds__(NW * 64, (RING == 2 ? 2 : 1)) k_grouped(const 
     else asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.aux0), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.ldx), "s"(lds_bytes));
     int t;                       // bijective for any tile count; only speed depends on the order
     {
-        const int nt = w.tiles_m * w.tiles_n * (TN && w.ksplit > 1 ? w.ksplit : 1);
+        const int nt = TN ? w.tile_cnt : w.tiles_m * w.tiles_n;
         const int q = nt / S, r = nt - q * S;
         if (idx >= q + (part < r ? 1 : 0)) return;                // padding block behind the chunk's last tile
-        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx;
+        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx + (TN ? w.tile_off : 0);
     }
     int ks = 0;                  // split-K chunk of this workgroup (weight gradients with a long K only)
     if constexpr (TN) {
