@@ -13,6 +13,9 @@ constexpr int kThreads = 256;          // 4 wavefronts of 64
 constexpr int kTileBytesK = 128;       // bytes of K per staged tile row: 64 bf16 or 32 f32
 constexpr int kRowAlign = 256;         // row counts of GEMM operands are padded to this (largest tile)
 constexpr int kLatentRows = 16;        // rows per latent work-item tile (many small blocks: the item is latency-bound)
+constexpr int kAdamRows = 16;          // k_adam tiles are kAdamRows x 64: measured 64 -> 32 -> 16 rows = 10.3 -> 9.8 -> 9.2 us on C2 (more,
+                                       // lighter workgroups balance better over 256 CUs and overlap each other's load and store
+                                       // phases); 8 rows (128 threads) 9.3 us and 16-byte segments in the transposed shadow
 constexpr int kCostHist = 4096;        // ring of per-step costs kept on the device
 
 // Work-item kinds.  Forward / dgrad kinds compute C[M,N] = sum_k A[m][k] * B[n][k] ("NT": both operands K-contiguous),

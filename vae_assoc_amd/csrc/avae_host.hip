@@ -863,7 +863,7 @@ void build_training_plan(avae_handle* h) {
         a.g = h->grad() + d.master;
         a.W = h->at<void>(d.W); a.Wt = h->at<void>(d.Wt);
         a.rows = d.in + 1; a.cols = d.out; a.ld = d.ld; a.ldt = d.ldt;
-        a.tiles_r = (a.rows + 63) / 64; a.tiles_c = (a.cols + 63) / 64; a.tile_base = base;
+        a.tiles_r = (a.rows + kAdamRows - 1) / kAdamRows; a.tiles_c = (a.cols + 63) / 64; a.tile_base = base;
         base += a.tiles_r * a.tiles_c;
         h->adam_items.push_back(a);
     };

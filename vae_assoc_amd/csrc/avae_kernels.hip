@@ -942,9 +942,11 @@ void launch_grouped_tn(int compute_dtype, int tile_cfg, const TnLaunchArgs& args
 //   theta -= lr_t*m/(sqrt(v)+eps)                       (epsilon outside the bias correction)
 // Tile-wise over each layer's [in+1][out] matrix so the same pass emits the compute-dtype shadow
 // W (row-major, dgrad operand) and, through an LDS transpose, W^T (forward operand).
-template <typename CT>
+template <typename CT, int TR>
 __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
-    __shared__ float T[64][65];
+    static_assert(TR % 16 == 0 && TR <= 64, "a pass covers 16 rows x 16 quads");
+    constexpr int NTH = kThreads;
+    __shared__ float T[TR][65];
     const int bid = blockIdx.x, tid = threadIdx.x;
     int it = 0;
     for (int i = 1; i < a.n_items; ++i)
@@ -952,7 +954,7 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
     const AdamItem w = a.items[it];
     const int t = bid - w.tile_base;
     const int tr = t / w.tiles_c, tc = t - tr * w.tiles_c;
-    const int r0 = tr * 64, c0 = tc * 64;
+    const int r0 = tr * TR, c0 = tc * 64;
 
     if (a.mode == 0 && tid == 0 && bid == 0) {              // step already counts this update (bumped by K_COST)
         const float c = *a.cost_src;
@@ -964,8 +966,8 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
 
     const int c4 = (tid & 15) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (tid >> 4) + 16 * i;
+    for (int i = 0; i < TR / (NTH / 16); ++i) {
+        const int r = (tid >> 4) + (NTH / 16) * i;
         const int grow = r0 + r, gcol = c0 + c4;
         float th[4] = {0.f, 0.f, 0.f, 0.f};
         if (grow < w.rows && gcol < w.cols) {
@@ -993,10 +995,11 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
         for (int e = 0; e < 4; ++e) T[r][c4 + e] = th[e];
     }
     lds_barrier();
-    const int r4 = (tid & 15) * 4;
+    constexpr int RL = TR / 4;                              // lanes along the rows of the transposed store
+    const int r4 = (tid % RL) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (tid >> 4) + 16 * i;
+    for (int i = 0; i < 64 / (NTH / RL); ++i) {
+        const int c = tid / RL + (NTH / RL) * i;
         const int gcol = c0 + c, grow = r0 + r4;
         if (gcol < w.cols && grow < w.rows) {
             float v[4];
@@ -1008,8 +1011,8 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
 }
 
 void launch_adam(int compute_dtype, const AdamArgs& a, int n_blocks, hipStream_t s) {
-    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_adam<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
-    else AVAE_LAUNCH((k_adam<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_adam<__bf16, kAdamRows>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else AVAE_LAUNCH((k_adam<float, kAdamRows>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
 // ------------------------------------------------------------------ input staging + eps
