@@ -1193,21 +1193,23 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
             // Fast path: the thread's 4 columns are 4 channels of one pixel (not straddling the mu | lv halves of the latent
             // mode), so the k x k walk over the patch gradients is done ONCE for all four with one 16-byte load per position; the
             // output stride so is 1 or 2 (mask / shift instead of % and /).  Each dP element is read exactly once overall.
+            // taps that reach this pixel: output position o = (i*d + pad - k)/so must be an integer in [0, O), i.e.
+            // k in [i*d + pad - (O-1)*so, i*d + pad] within [0, k), in steps of so from the right residue -- the walk visits only
+            // those (the flatten stage, k = 28, has exactly one)
+            const int th = ih * g.d + g.pad, tw = iw * g.d + g.pad;
+            int kh_lo = max(0, th - (g.OH - 1) * g.so), kw_lo = max(0, tw - (g.OW - 1) * g.so);
+            kh_lo += (th - kh_lo) % g.so;                 // th >= kh_lo >= 0
+            kw_lo += (tw - kw_lo) % g.so;
+            const int kh_hi = min(g.k - 1, th), kw_hi = min(g.k - 1, tw);
             const bool quad = (g.Cin & 3) == 0 && (g.so == 1 || g.so == 2) && cc + 3 < C && (!latent || (w.nz & 3) == 0);
             if (quad) {
                 const int ci0 = latent ? (cc < w.nz ? cc : cc - w.nz) : cc;
                 const int smask = g.so - 1, sshift = g.so >> 1;
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int kh = 0; kh < g.k; ++kh) {
-                    const int nh = ih * g.d + g.pad - kh;
-                    if (nh < 0 || (nh & smask)) continue;
-                    const int oh = nh >> sshift;
-                    if (oh >= g.OH) continue;
-                    for (int kw = 0; kw < g.k; ++kw) {
-                        const int nw = iw * g.d + g.pad - kw;
-                        if (nw < 0 || (nw & smask)) continue;
-                        const int ow = nw >> sshift;
-                        if (ow >= g.OW) continue;
+                for (int kh = kh_lo; kh <= kh_hi; kh += g.so) {
+                    const int oh = (th - kh) >> sshift;
+                    for (int kw = kw_lo; kw <= kw_hi; kw += g.so) {
+                        const int ow = (tw - kw) >> sshift;
                         float t[4];
                         load4<float>(w.dP + (size_t)((b * g.OH + oh) * g.OW + ow) * w.lddp + (kh * g.k + kw) * g.Cin + ci0, t);
 #pragma unroll
@@ -1234,16 +1236,10 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
                 if (col >= C) continue;
                 const int ci = latent ? (col < w.nz ? col : col - w.nz) : col;
                 float acc = 0.0f;
-                for (int kh = 0; kh < g.k; ++kh) {
-                    const int nh = ih * g.d + g.pad - kh;
-                    if (nh < 0 || nh % g.so) continue;
-                    const int oh = nh / g.so;
-                    if (oh >= g.OH) continue;
-                    for (int kw = 0; kw < g.k; ++kw) {
-                        const int nw = iw * g.d + g.pad - kw;
-                        if (nw < 0 || nw % g.so) continue;
-                        const int ow = nw / g.so;
-                        if (ow >= g.OW) continue;
+                for (int kh = kh_lo; kh <= kh_hi; kh += g.so) {
+                    const int oh = (th - kh) / g.so;
+                    for (int kw = kw_lo; kw <= kw_hi; kw += g.so) {
+                        const int ow = (tw - kw) / g.so;
                         acc += w.dP[(size_t)((b * g.OH + oh) * g.OW + ow) * w.lddp + (kh * g.k + kw) * g.Cin + ci];
                     }
                 }
@@ -1281,13 +1277,22 @@ __global__ void __launch_bounds__(kThreads) k_reduce(ReduceArgs a) {
     const ReduceSeg& g = a.seg[it];
     const int i = ((bid - g.block_base) * kThreads + (int)threadIdx.x) * 4;       // n and stride are multiples of 4
     if (i >= g.n) return;
-    float acc[4];
-    load4<float>(g.src + i, acc);
-    for (int s = 1; s < g.parts; ++s) {
-        float v[4];
-        load4<float>(g.src + (size_t)s * g.stride + i, v);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // slices are added in index order (reproducible); eight loads are in flight at a time -- one load per loop trip would
+    // serialise `parts` (up to ~100) memory round trips
+    for (int s0 = 0; s0 < g.parts; s0 += 8) {
+        float v[8][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        for (int u = 0; u < 8; ++u) {
+            const int sl = min(s0 + u, g.parts - 1);        // clamped: the surplus loads are discarded below
+            load4<float>(g.src + (size_t)sl * g.stride + i, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < g.parts) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[u][e];
+            }
     }
     store4<float>(g.dst + i, acc);
 }
