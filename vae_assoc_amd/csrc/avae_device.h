@@ -171,7 +171,8 @@ struct PrepArgs {
 };
 
 // Fixed-order sum of the split-K slices of a weight gradient: dst[i] = sum_s src[s*stride + i]  (no atomics: reproducible).
-struct ReduceSeg { float* dst; const float* src; int n, parts; long long stride; int block_base, pad; };
+struct ReduceSeg { float* dst; const float* src; int n, parts; long long stride; int block_base;
+                   int dst_ld; };   // dst_ld > 0: element i goes to dst[i * dst_ld] (a one-column gradient in a padded matrix)
 constexpr int kMaxReduceSegs = 24;
 struct ReduceArgs { ReduceSeg seg[kMaxReduceSegs]; int n_seg; };
 
@@ -205,6 +206,30 @@ struct Col2imSeg {
     int tiles_r, tiles_c, tile_base;
 };
 struct Col2imArgs { Col2imSeg seg[kMaxMod]; int n_seg; };
+
+// The last transposed-conv stage (G2 channels -> ONE 28x28 map, vae_assoc.py:274-278) as direct kernels.  On the GEMM path
+// its single output channel is one useful column of a 32-wide tile, its patch matrix is 180 MB and its fp32 patch gradients
+// 321 MB per step at batch 256; computed directly the stage reads its 1.6 MB input and the 400 filter taps.
+// One workgroup per image, the image staged in LDS:
+//   mode 0  forward    : Y[p] = act(bias + sum_taps X[b, ih, iw, :] . F[kh, kw, :])
+//   mode 1  input grad : dX[b, ih, iw, c] = act_in'(X) * sum_taps dY[b, oh, ow] * F[kh, kw, c]
+//   mode 2  filter grad: part[image][Kp]   (summed over images by k_colsum)
+constexpr int kThinIn = 4096, kThinOut = 1024, kThinF = 1024;   // k_thin: one image per workgroup, staged in LDS (floats)
+struct ThinSeg {
+    ConvGeom g;
+    const void* X;           // stage input = stored output of the producing stage, [b*src_sb + pixel*src_sp + c]
+    const void* Wt;          // filter shadow [1][ldt]: taps (kh, kw, c), bias at index k*k*Cin
+    void* Y; int ldy;        // stage output, column 0 of [rows][ldy]
+    int act, act_in;         // transfer function of this stage / of the producing stage
+    const void* dY; int lddy;   // gradient w.r.t. this stage's pre-activation output, column 0
+    void* dX; int lddx;      // gradient w.r.t. the producing stage's pre-activation output [pixels][lddx]
+    float* part;             // mode 2: [blocks][Kp]
+    int Kp;                  // roundup(k*k*Cin + 1, 4)
+    int block_base;
+};
+struct ThinArgs { ThinSeg seg[kMaxMod]; int n_seg; int mode; };
+void launch_thin(int compute_dtype, const ThinArgs& a, int n_blocks, hipStream_t s);
+void launch_colsum(const ReduceArgs& a, int n_blocks, hipStream_t s);
 
 void launch_gather(int compute_dtype, const GatherArgs& a, int n_blocks, hipStream_t s);
 void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStream_t s);

@@ -74,6 +74,9 @@ struct ConvStage {
     int lddp = 0;
     int ksplit = 1, kchunk = 0;    // weight gradient: K = rows is cut into ksplit chunks of kchunk K tiles (see WorkItem)
     size_t part = 0;       // fp32 slices [ksplit][K+1][d.ld] of the split weight gradient
+    bool thin = false;     // one output channel: direct kernels (k_thin) instead of im2col -> GEMM -> col2im in the training plan
+    size_t thin_part = 0;  // its filter-gradient partial sums [thin_blocks][Kp]
+    int thin_blocks = 0, thin_kp = 0;
 };
 
 struct Mod {
@@ -100,6 +103,7 @@ struct Launch {
     GatherArgs ga{};
     Col2imArgs ca{};
     ReduceArgs ra{};
+    ThinArgs ta{};
 };
 
 struct TimingRec { hipEvent_t a, b; int launch_name; };
@@ -152,12 +156,12 @@ struct avae_handle {
 
 namespace {
 
-Act make_act(Bump& b, int width, bool ones, int rows, int KU, int es) {
+Act make_act(Bump& b, int width, bool ones, int rows, int KU, int es, int ld = 0) {
     Act a;
     a.width = width;
     a.rows = rows;
     a.ones = ones;
-    a.ld = (int)rup(width + 1, KU);
+    a.ld = ld > 0 ? ld : (int)rup(width + 1, KU);       // ld given: a buffer that is never a GEMM operand
     a.rm = b.take(rup(rows, kRowAlign) * (size_t)a.ld * es);
     return a;
 }
@@ -265,9 +269,13 @@ void plan_memory(avae_handle* h) {
                 const int K = k * k * Cin, rows = B * OH * OH;
                 st.d = make_dense(b, pint, K, Cout, KU, es, flat == 3);
                 st.P = make_act(b, K, bias, rows, KU, es);
+                const bool thin = Cout == 1 && plain_out && IH * IH * Cin <= kThinIn && OH * OH <= kThinOut && K + 1 <= kThinF &&
+                                  !std::getenv("AVAE_NO_THIN");
                 if (plain_out) {     // hidden conv stage: own output / gradient buffers
-                    st.Y = make_act(b, Cout, false, rows, KU, es);
-                    st.dY = make_act(b, Cout, false, rows, KU, es);
+                    // (the direct stage's one-channel maps are read and written pixel by pixel, never as a GEMM operand: 8
+                    // elements per pixel instead of a K-padded row of 64 keep them 8x smaller -- 3 MB instead of 26 MB)
+                    st.Y = make_act(b, Cout, false, rows, KU, es, thin ? 8 : 0);
+                    st.dY = make_act(b, Cout, false, rows, KU, es, thin ? 8 : 0);
                 }
                 st.lddp = (int)rup(K, 8);
                 st.dP = b.take((size_t)rows * st.lddp * 4);
@@ -280,6 +288,12 @@ void plan_memory(avae_handle* h) {
                         st.ksplit = (steps + st.kchunk - 1) / st.kchunk;
                         st.part = b.take((size_t)st.ksplit * (K + 1) * st.d.ld * 4);
                     }
+                }
+                if (thin) {
+                    st.thin = true;
+                    st.thin_kp = (int)rup(K + 1, 4);
+                    st.thin_blocks = B;                   // filter gradient: one workgroup per image
+                    st.thin_part = b.take((size_t)st.thin_blocks * st.thin_kp * 4);
                 }
                 pflat += (size_t)K * Cout + (flat == 0 ? 0 : Cout);
                 return st;
@@ -463,6 +477,20 @@ struct Builder {
         WorkItem w = gemm_item(K_DGRAD_F32, conv_rows(st), st.d.in, K_of(st.d.out), p<void>(dA.rm), dA.ld, p<void>(st.d.W), st.d.ld);
         w.out0 = p<void>(st.dP); w.ld0 = st.lddp;
         return w;
+    }
+    // the one-output-channel stage as direct kernels: `prev` produced its input
+    ThinSeg thin_seg(const ConvStage& st, const ConvStage& prev) {
+        ThinSeg t;
+        std::memset(&t, 0, sizeof(t));
+        t.g = st.g; t.g.B = B;
+        t.X = p<void>(prev.Y.rm);
+        t.Wt = p<void>(st.d.Wt);
+        t.Y = p<void>(st.Y.rm); t.ldy = st.Y.ld;
+        t.act = st.act; t.act_in = prev.act;
+        t.dY = p<void>(st.dY.rm); t.lddy = st.dY.ld;
+        t.dX = p<void>(prev.dY.rm); t.lddx = prev.dY.ld;
+        t.part = p<float>(st.thin_part); t.Kp = st.thin_kp;
+        return t;
     }
     GatherSeg gather_seg(const ConvStage& st, const void* src) {
         GatherSeg g;
@@ -705,6 +733,23 @@ void build_training_plan(avae_handle* h) {
         L.blocks = base;
         if (base > 0) dst.push_back(L);
     };
+    // the decoder's last transposed conv (one output channel) runs as direct kernels: mode 0 forward, 1 input gradient,
+    // 2 filter-gradient partial sums
+    auto thin_launch = [&](const std::string& name, std::vector<Launch>& dst, int mode) {
+        Launch L;
+        L.name = name; L.type = 4;
+        L.ta.mode = mode;
+        int base = 0;
+        for (Mod& md : h->mods) if (md.conv && md.cdec[3].thin) {
+            ThinSeg t = bd.thin_seg(md.cdec[3], md.cdec[2]);
+            t.block_base = base;
+            base += h->B;                                  // one workgroup per image in every mode
+            L.ta.seg[L.ta.n_seg++] = t;
+        }
+        L.blocks = base;
+        if (base > 0) dst.push_back(L);
+    };
+    auto is_thin = [&](int i) { bool t = false; for (const Mod& md : h->mods) t = t || (md.conv && md.cdec[i].thin); return t; };
     bool any_conv = false;
     for (const Mod& md : h->mods) any_conv = any_conv || md.conv;
     // ---- forward.  Modalities with fewer hidden layers simply sit out a launch; data dependencies
@@ -729,6 +774,7 @@ void build_training_plan(avae_handle* h) {
         });
     if (any_conv) {   // deconv decoder: (im2col of the dilated input, GEMM + bias + sigmoid) x 4, then flatten for the dense output
         for (int i = 0; i < 4; ++i) {
+            if (is_thin(i)) { thin_launch("conv_dec" + std::to_string(i + 1) + "_direct", h->fwd, 0); continue; }
             gather_launch("conv_dec" + std::to_string(i + 1) + "_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
                           [&](Mod& md) { return i == 0 ? h->at<void>(md.Z.rm) : h->at<void>(md.cdec[i - 1].Y.rm); });
             group("conv_dec" + std::to_string(i + 1), h->fwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_fwd(md.cdec[i])); });
@@ -753,8 +799,11 @@ void build_training_plan(avae_handle* h) {
     });
     if (any_conv) {
         for (int i = 4; i >= 1; --i) {       // stage i's patch gradients -> dY of stage i-1; then stage i-1's dgrad GEMM
-            col2im_launch("conv_dec" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
-                          [&](Mod& md) -> const ConvStage* { return &md.cdec[i - 1]; });
+            // (a direct stage has no patch gradients: its k_thin launch wrote the producing stage's gradient itself)
+            if (!(i <= 3 && is_thin(i)))
+                col2im_launch("conv_dec" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
+                              [&](Mod& md) -> const ConvStage* { return &md.cdec[i - 1]; });
+            if (i - 1 <= 3 && is_thin(i - 1)) { thin_launch("conv_bwd_dec" + std::to_string(i) + "_direct", h->bwd, 1); continue; }
             group("conv_bwd_dec" + std::to_string(i), h->bwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_dgrad(md.cdec[i - 1], md.cdec[i - 1].dY)); });
         }
         // first decoder stage: its input is z -> latent mode turns dz into [dmu | dlv]
@@ -796,7 +845,7 @@ void build_training_plan(avae_handle* h) {
         for (Mod& md : h->mods) {
             if (md.conv) {
                 wg.push_back(bd.wgrad_stage(md.cdec[4], md.dO));
-                for (int i = 3; i >= 0; --i) wg.push_back(bd.wgrad_stage(md.cdec[i], md.cdec[i].dY));
+                for (int i = 3; i >= 0; --i) if (!md.cdec[i].thin) wg.push_back(bd.wgrad_stage(md.cdec[i], md.cdec[i].dY));
                 wg.push_back(bd.wgrad_stage(md.cenc[3], md.dH));
                 for (int i = 2; i >= 0; --i) wg.push_back(bd.wgrad_stage(md.cenc[i], md.cenc[i].dY));
                 continue;
@@ -828,6 +877,21 @@ void build_training_plan(avae_handle* h) {
         for (size_t c = 0; c < chunks.size(); ++c) {
             group("wgrad" + (chunks.size() > 1 ? std::to_string(c + 1) : std::string()), h->wgrad,
                   [&] { for (const WorkItem& w : chunks[c]) h->items.push_back(w); });
+        }
+        thin_launch("conv_dec4_wgrad_direct", h->wgrad, 2);
+        {   // ... and its per-image partial sums -> the gradient buffer (one column of the padded matrix)
+            Launch R;
+            R.name = "conv_dec4_wgrad_sum"; R.type = 5;
+            int base = 0;
+            for (Mod& md : h->mods) if (md.conv && md.cdec[3].thin) {
+                const ConvStage& st = md.cdec[3];
+                ReduceSeg& g = R.ra.seg[R.ra.n_seg++];
+                g.dst = h->grad() + st.d.master; g.src = h->at<float>(st.thin_part);
+                g.n = st.d.in + 1; g.parts = st.thin_blocks; g.stride = st.thin_kp; g.dst_ld = st.d.ld;
+                g.block_base = base; base += (g.n + 15) / 16;
+            }
+            R.blocks = base;
+            if (base > 0) h->wgrad.push_back(R);
         }
         {   // the split-K slices of the conv stages' weight gradients -> the gradient buffer, in fixed order
             Launch R;
@@ -961,6 +1025,8 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         if (L.type == 1) launch_gather(h->cfg.compute_dtype, L.ga, L.blocks, s);
         else if (L.type == 2) launch_col2im(h->cfg.compute_dtype, L.ca, L.blocks, s);
         else if (L.type == 3) launch_reduce(L.ra, L.blocks, s);
+        else if (L.type == 4) launch_thin(h->cfg.compute_dtype, L.ta, L.blocks, s);
+        else if (L.type == 5) launch_colsum(L.ra, L.blocks, s);
         else if (L.tn) launch_grouped_tn(h->cfg.compute_dtype, L.cfg, L.targs, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to

@@ -1269,6 +1269,206 @@ void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStre
     else AVAE_LAUNCH((k_col2im<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
+// ------------------------------------------------------------------ single-output-channel transposed-conv stage, direct
+// n / q for the two strides the branch uses (1, 2) without an integer division; `ok` = divisible
+__device__ __forceinline__ int div_small(int n, int q, bool& ok) {
+    if (q == 1) { ok = true; return n; }
+    if (q == 2) { ok = !(n & 1); return n >> 1; }
+    ok = n % q == 0;
+    return n / q;
+}
+
+// non-negative remainder
+__device__ __forceinline__ int mod_small(int n, int q) {
+    if (q == 1) return 0;
+    if (q == 2) return n & 1;
+    const int r = n % q;
+    return r < 0 ? r + q : r;
+}
+
+// One workgroup per image in every mode: the image's input planes (IH*IW*Cin <= kThinIn), its output(-gradient) map
+// (OH*OW <= kThinOut) and the filter (Kp <= kThinF) sit in LDS as fp32; products and sums are fp32 (operands were rounded to
+// the compute type when they were stored, as on the GEMM path).
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
+    __shared__ __attribute__((aligned(16))) float sx[kThinIn];
+    __shared__ __attribute__((aligned(16))) float sf[kThinF + 4];
+    __shared__ float sdy[kThinOut];
+    __shared__ float sred[64];
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
+    const ThinSeg& w = a.seg[it];
+    const ConvGeom g = w.g;
+    const int b = bid - w.block_base;                     // image
+    const CT* X = reinterpret_cast<const CT*>(w.X) + (size_t)b * g.src_sb;
+    const CT* F = reinterpret_cast<const CT*>(w.Wt);
+    const int K = g.k * g.k * g.Cin, Cin = g.Cin;
+    const int npi = g.IH * g.IW, npo = g.OH * g.OW;
+    if (a.mode != 1) {                                    // input planes
+        if ((Cin & 3) == 0) {
+            const int Q = Cin >> 2;
+            for (int i = tid; i < npi * Q; i += kThreads) {
+                const int px = i / Q, c = (i - px * Q) * 4;
+                float v[4];
+                load4<CT>(X + (size_t)px * g.src_sp + c, v);
+                *reinterpret_cast<f32x4*>(sx + px * Cin + c) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        } else {
+            for (int i = tid; i < npi * Cin; i += kThreads) {
+                const int px = i / Cin, c = i - px * Cin;
+                sx[i] = ct_load<CT>(X + (size_t)px * g.src_sp + c);
+            }
+        }
+    }
+    if (a.mode != 2)                                      // filter taps (+ bias at K)
+        for (int i = tid; i < K + 1; i += kThreads) sf[i] = ct_load<CT>(F + i);
+    if (a.mode != 0) {                                    // output-gradient map
+        const CT* dY = reinterpret_cast<const CT*>(w.dY) + (size_t)b * npo * w.lddy;
+        for (int i = tid; i < npo; i += kThreads) sdy[i] = ct_load<CT>(dY + (size_t)i * w.lddy);
+    }
+    lds_barrier();
+
+    if (a.mode == 0) {
+        // Y[oh, ow] = act(bias + sum over taps (kh, kw) with ih = (oh*so + kh - pad)/d an integer in [0, IH) (same for w))
+        CT* Y = reinterpret_cast<CT*>(w.Y) + (size_t)b * npo * w.ldy;
+        for (int p = tid; p < npo; p += kThreads) {
+            const int oh = p / g.OW, ow = p - oh * g.OW;
+            const int bh = oh * g.so - g.pad, bw = ow * g.so - g.pad;
+            int kh0 = max(0, -bh), kw0 = max(0, -bw);
+            kh0 += mod_small(-(bh + kh0), g.d);           // first tap whose source row exists: (bh + kh) divisible by d
+            kw0 += mod_small(-(bw + kw0), g.d);
+            bool ok_;
+            float acc = g.ones ? sf[K] : 0.0f;
+            for (int kh = kh0, ih = div_small(bh + kh0, g.d, ok_); kh < g.k && ih < g.IH; kh += g.d, ++ih)
+                for (int kw = kw0, iw = div_small(bw + kw0, g.d, ok_); kw < g.k && iw < g.IW; kw += g.d, ++iw) {
+                    const float* xr = sx + (ih * g.IW + iw) * Cin;
+                    const float* fr = sf + (kh * g.k + kw) * Cin;
+                    if ((Cin & 3) == 0) {
+                        for (int c = 0; c < Cin; c += 4) {
+                            const f32x4 x = *reinterpret_cast<const f32x4*>(xr + c), f = *reinterpret_cast<const f32x4*>(fr + c);
+                            acc += x[0] * f[0]; acc += x[1] * f[1]; acc += x[2] * f[2]; acc += x[3] * f[3];
+                        }
+                    } else {
+                        for (int c = 0; c < Cin; ++c) acc += xr[c] * fr[c];
+                    }
+                }
+            Y[(size_t)p * w.ldy] = (CT)act_fwd(w.act, acc);
+        }
+    } else if (a.mode == 1) {
+        // dX[ih, iw, c] = act_in'(X) * sum over taps with oh = (ih*d + pad - kh)/so an integer in [0, OH) of dY[oh, ow] * F[kh, kw, c]
+        const int Q = (Cin + 3) >> 2;
+        CT* dX = reinterpret_cast<CT*>(w.dX) + (size_t)b * npi * w.lddx;
+        for (int idx = tid; idx < npi * Q; idx += kThreads) {
+            const int pix = idx / Q, c0 = (idx - pix * Q) * 4;
+            const int ih = pix / g.IW, iw = pix - ih * g.IW;
+            const int th = ih * g.d + g.pad, tw = iw * g.d + g.pad;
+            int kh_lo = max(0, th - (g.OH - 1) * g.so), kw_lo = max(0, tw - (g.OW - 1) * g.so);
+            kh_lo += mod_small(th - kh_lo, g.so);
+            kw_lo += mod_small(tw - kw_lo, g.so);
+            const int kh_hi = min(g.k - 1, th), kw_hi = min(g.k - 1, tw);
+            const int nc = min(4, Cin - c0);
+            bool ok_;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int kh = kh_lo; kh <= kh_hi; kh += g.so) {
+                const float* yr = sdy + div_small(th - kh, g.so, ok_) * g.OW;
+                for (int kw = kw_lo; kw <= kw_hi; kw += g.so) {
+                    const float dy = yr[div_small(tw - kw, g.so, ok_)];
+                    const float* fr = sf + (kh * g.k + kw) * Cin + c0;     // (sf is padded: reading past nc is harmless)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += dy * fr[e];
+                }
+            }
+            const CT* xp = X + (size_t)pix * g.src_sp + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nc) acc[e] *= act_bwd(w.act_in, ct_load<CT>(xp + e));
+            store_row<CT>(dX + (size_t)pix * w.lddx + c0, acc, nc);
+        }
+    } else {
+        // dF[kh, kw, c] = sum_{ih, iw} X[ih, iw, c] * dY[(ih*d + pad - kh)/so, (iw*d + pad - kw)/so]; thread t owns tap t (and
+        // t + 256, ...); part[image][K] = bias gradient = sum of the map
+        {   // bias: 64 strided partial sums, then thread 0 adds them in order
+            if (tid < 64) {
+                float sacc = 0.0f;
+                for (int i = tid; i < npo; i += 64) sacc += sdy[i];
+                sred[tid] = sacc;
+            }
+            lds_barrier();
+        }
+        for (int t = tid; t < w.Kp; t += kThreads) {
+            float acc = 0.0f;
+            if (t < K) {
+                const int kp = t / Cin, c = t - kp * Cin, kh = kp / g.k, kw = kp - kh * g.k;
+                for (int ih = 0; ih < g.IH; ++ih) {
+                    bool okh;
+                    const int oh = div_small(ih * g.d + g.pad - kh, g.so, okh);
+                    if (!okh || oh < 0 || oh >= g.OH) continue;
+                    const float* xr = sx + ih * g.IW * Cin + c;
+                    const float* yr = sdy + oh * g.OW;
+                    if (g.so == 1) {                    // ow = iw*d + pad - kw: a contiguous run of iw, no test inside the loop
+                        const int off = g.pad - kw;
+                        const int lo = off >= 0 ? 0 : (-off + g.d - 1) / g.d;
+                        const int hi = min(g.IW - 1, off <= g.OW - 1 ? (g.OW - 1 - off) / g.d : -1);
+#pragma unroll 7
+                        for (int iw = lo; iw <= hi; ++iw) acc += xr[iw * Cin] * yr[iw * g.d + off];
+                    } else {
+                        for (int iw = 0; iw < g.IW; ++iw) {
+                            bool okw;
+                            const int ow = div_small(iw * g.d + g.pad - kw, g.so, okw);
+                            if (okw && ow >= 0 && ow < g.OW) acc += xr[iw * Cin] * yr[ow];
+                        }
+                    }
+                }
+            } else if (t == K && g.ones) {
+                for (int i = 0; i < 64; ++i) acc += sred[i];
+            }
+            w.part[(size_t)b * w.Kp + t] = acc;
+        }
+    }
+}
+
+// Column sums of the direct stage's per-image partial filter gradients: dst[i*dst_ld] = sum_s src[s*stride + i].  16 lanes of
+// a workgroup share an element, lane group q adding slices q, q+16, ... in order; the 16 group sums are then added in
+// order: a fixed tree, reproducible.
+__global__ void __launch_bounds__(kThreads) k_colsum(ReduceArgs a) {
+    __shared__ float red[16][17];
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
+    const ReduceSeg& g = a.seg[it];
+    const int e = tid & 15, q = tid >> 4;
+    const int i = (bid - g.block_base) * 16 + e;
+    float acc = 0.0f;
+    if (i < g.n) {
+        for (int s0 = q; s0 < g.parts; s0 += 16 * 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = g.src[(size_t)min(s0 + 16 * u, g.parts - 1) * g.stride + i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (s0 + 16 * u < g.parts) acc += v[u];
+        }
+    }
+    red[q][e] = acc;
+    lds_barrier();
+    if (q == 0 && i < g.n) {
+        float t = red[0][e];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][e];
+        g.dst[(size_t)i * (g.dst_ld > 0 ? g.dst_ld : 1)] = t;
+    }
+}
+
+void launch_colsum(const ReduceArgs& a, int n_blocks, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    AVAE_LAUNCH(k_colsum, dim3(n_blocks), dim3(kThreads), 0, s, a);
+}
+
+void launch_thin(int compute_dtype, const ThinArgs& a, int n_blocks, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_thin<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else AVAE_LAUNCH((k_thin<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+}
+
 // ------------------------------------------------------------------ split-K reduction
 __global__ void __launch_bounds__(kThreads) k_reduce(ReduceArgs a) {
     const int bid = blockIdx.x;
