@@ -192,6 +192,7 @@ struct GatherSeg {
     const void* src;
     void* P; int ldp;
     int tiles_r, tiles_c, tile_base;
+    int cl, rpt;                      // tile shape, see Col2imSeg
 };
 struct GatherArgs { GatherSeg seg[kMaxMod]; int n_seg; };
 // k_col2im: fp32 patch gradients dP -> gradient of the layer input, times act'(stored input), written
@@ -204,6 +205,8 @@ struct Col2imSeg {
     void* dA; int lda;                // [B*IH*IW][lda]
     const float* g0; int nz;          // latent mode when g0 != nullptr
     int tiles_r, tiles_c, tile_base;
+    int cl, rpt;                      // tile shape: cl (1..16, power of two) lanes of 4 columns, rpt (1 or 4) rows per thread:
+                                      // (256/cl)*rpt rows x 4*cl columns -- narrow outputs get tall tiles, short ones many tiles
 };
 struct Col2imArgs { Col2imSeg seg[kMaxMod]; int n_seg; };
 

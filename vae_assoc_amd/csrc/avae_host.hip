@@ -492,6 +492,17 @@ struct Builder {
         t.part = p<float>(st.thin_part); t.Kp = st.thin_kp;
         return t;
     }
+    // tile shape of the element-wise conv helpers: 4*cl columns (cl lanes of a quad each, a power of two <= 16) x (256/cl)*rpt
+    // rows; outputs with few columns get tall tiles instead of idle lanes, outputs with few rows one row per thread so
+    // that there are enough workgroups
+    static void tile_shape(int rows, int cols, int* cl, int* rpt, int* tiles_r, int* tiles_c) {
+        int c = 1;
+        while (c < 16 && 4 * c < cols) c *= 2;
+        *cl = c;
+        *rpt = (long)rows * ((cols + 4 * c - 1) / (4 * c)) >= 4L * (kThreads / c) * 512 ? 4 : 1;      // >= 512 workgroups at 4 rows/thread
+        const int tr = (kThreads / c) * *rpt;
+        *tiles_r = (rows + tr - 1) / tr; *tiles_c = (cols + 4 * c - 1) / (4 * c);
+    }
     GatherSeg gather_seg(const ConvStage& st, const void* src) {
         GatherSeg g;
         std::memset(&g, 0, sizeof(g));
@@ -499,7 +510,7 @@ struct Builder {
         g.src = src;
         g.P = p<void>(st.P.rm); g.ldp = st.P.ld;
         const int M = conv_rows(st), KC = st.d.in + (st.bias ? 1 : 0);
-        g.tiles_r = (M + 63) / 64; g.tiles_c = (KC + 63) / 64;
+        tile_shape(M, KC, &g.cl, &g.rpt, &g.tiles_r, &g.tiles_c);
         return g;
     }
     // gradient of stage `st`'s input: into the producing stage `prev` (nullptr: latent mode -> dH of `md`)
@@ -519,7 +530,7 @@ struct Builder {
             C = 2 * h->nz;
         }
         const int R = B * st.g.IH * st.g.IW;
-        c.tiles_r = (R + 63) / 64; c.tiles_c = (C + 63) / 64;
+        tile_shape(R, C, &c.cl, &c.rpt, &c.tiles_r, &c.tiles_c);
         return c;
     }
     // dW_aug[m][n] = sum_k X_aug[k][m] * dA[k][n]: both operands are read as stored (row = sample k), see the K-major

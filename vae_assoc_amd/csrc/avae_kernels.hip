@@ -1122,10 +1122,11 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
     const ConvGeom g = w.g;
     const int t = bid - w.tile_base;
     const int tr = t / w.tiles_c, tc = t - tr * w.tiles_c;
-    const int r0 = tr * 64, c0 = tc * 64;
+    const int rstep = kThreads / w.cl;                      // rows per pass
+    const int r0 = tr * rstep * w.rpt, c0 = tc * 4 * w.cl;
     const int M = g.B * g.OH * g.OW, K = g.k * g.k * g.Cin, KC = K + (g.ones ? 1 : 0);
     const CT* src = reinterpret_cast<const CT*>(w.src);
-    const int c4 = (tid & 15) * 4;
+    const int c4 = (tid & (w.cl - 1)) * 4;
     const int kc = c0 + c4;
     // The thread's 4 consecutive patch columns: with Cin % 4 == 0 they are 4 channels of ONE filter position (kh, kw), so the
     // position is decoded once per thread (not per element and row) and the 4 channels are one vector load; the dilation d is 1 or 2
@@ -1133,9 +1134,8 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
     const bool quad = (g.Cin & 3) == 0 && (g.d == 1 || g.d == 2) && kc < K;
     const int kpos = quad ? kc / g.Cin : 0, ci0 = quad ? kc - kpos * g.Cin : 0, kh0 = kpos / g.k, kw0 = kpos - kh0 * g.k;
     const int dmask = g.d - 1, dshift = g.d >> 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (tid >> 4) + 16 * i;
+    auto row_pass = [&](int i) {
+        const int r = tid / w.cl + rstep * i;
         const int m = r0 + r;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (m < M && kc < KC) {
@@ -1166,6 +1166,12 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
             }
             store_row<CT>(reinterpret_cast<CT*>(w.P) + (size_t)m * w.ldp + kc, v, KC - kc);
         }
+    };
+    if (w.rpt == 4) {        // unrolled: the four rows' loads are in flight together
+#pragma unroll
+        for (int i = 0; i < 4; ++i) row_pass(i);
+    } else {
+        row_pass(0);
     }
 }
 
@@ -1178,14 +1184,14 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
     const ConvGeom g = w.g;
     const int t = bid - w.tile_base;
     const int tr = t / w.tiles_c, tc = t - tr * w.tiles_c;
-    const int r0 = tr * 64, c0 = tc * 64;
+    const int rstep = kThreads / w.cl;                      // rows per pass
+    const int r0 = tr * rstep * w.rpt, c0 = tc * 4 * w.cl;
     const int R = g.B * g.IH * g.IW;                      // input pixels
     const bool latent = w.g0 != nullptr;
     const int C = latent ? 2 * w.nz : g.Cin;              // output columns
-    const int c4 = (tid & 15) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (tid >> 4) + 16 * i;
+    const int c4 = (tid & (w.cl - 1)) * 4;
+    auto row_pass = [&](int i) {
+        const int r = tid / w.cl + rstep * i;
         const int pix = r0 + r, cc = c0 + c4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (pix < R && cc < C) {
@@ -1255,6 +1261,12 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
             }
             store_row<CT>(reinterpret_cast<CT*>(w.dA) + (size_t)pix * w.lda + cc, v, C - cc);
         }
+    };
+    if (w.rpt == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) row_pass(i);
+    } else {
+        row_pass(0);
     }
 }
 
