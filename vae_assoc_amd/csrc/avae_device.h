@@ -234,6 +234,12 @@ struct ThinArgs { ThinSeg seg[kMaxMod]; int n_seg; int mode; };
 void launch_thin(int compute_dtype, const ThinArgs& a, int n_blocks, hipStream_t s);
 void launch_colsum(const ReduceArgs& a, int n_blocks, hipStream_t s);
 
+// Adjoint filter shadow of a transposed-conv stage: Wadj[ci][(kh', kw', co)] = Wt[co][((k-1-kh')*k + (k-1-kw'))*Cin + ci], the B
+// operand of the stage's input gradient computed as a GEMM on the patch matrix of its OUTPUT gradient.
+struct WadjSeg { const void* Wt; void* Wadj; int ldt, ldadj, k, Cin, Cout, block_base; };
+struct WadjArgs { WadjSeg seg[2 * kMaxMod]; int n_seg; };
+void launch_wadj(int compute_dtype, const WadjArgs& a, int n_blocks, hipStream_t s);
+
 void launch_gather(int compute_dtype, const GatherArgs& a, int n_blocks, hipStream_t s);
 void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStream_t s);
 

@@ -74,6 +74,10 @@ struct ConvStage {
     int lddp = 0;
     int ksplit = 1, kchunk = 0;    // weight gradient: K = rows is cut into ksplit chunks of kchunk K tiles (see WorkItem)
     size_t part = 0;       // fp32 slices [ksplit][K+1][d.ld] of the split weight gradient
+    bool adj = false;      // transposed conv whose input gradient is a GEMM on the patch matrix of its OUTPUT gradient
+    Act Padj;              // that patch matrix, rows = B*IH*IW, width = k*k*Cout
+    size_t Wadj = 0;       // adjoint filter shadow [Cin (padded)][ldadj]
+    int ldadj = 0;
     bool thin = false;     // one output channel: direct kernels (k_thin) instead of im2col -> GEMM -> col2im in the training plan
     size_t thin_part = 0;  // its filter-gradient partial sums [thin_blocks][Kp]
     int thin_blocks = 0, thin_kp = 0;
@@ -104,6 +108,7 @@ struct Launch {
     Col2imArgs ca{};
     ReduceArgs ra{};
     ThinArgs ta{};
+    WadjArgs wa{};
 };
 
 struct TimingRec { hipEvent_t a, b; int launch_name; };
@@ -288,6 +293,15 @@ void plan_memory(avae_handle* h) {
                         st.ksplit = (steps + st.kchunk - 1) / st.kchunk;
                         st.part = b.take((size_t)st.ksplit * (K + 1) * st.d.ld * 4);
                     }
+                }
+                // transposed convs that upsample (d > 1) or pad heavily have an OUTPUT far larger than their input: the fp32 patch
+                // gradients [B*OH*OW][k*k*Cin] of the plain path (160 MB for 7x7x32 -> 14x14x16) are replaced by the compute-type
+                // patch matrix of the output gradient, [B*IH*IW][k*k*Cout] (11 MB), times the adjoint filter
+                if (flat == 1 && plain_out && !thin && IH > 1 && (long)IH * IH * Cout < (long)OH * OH * Cin * 2 && !std::getenv("AVAE_NO_ADJ")) {
+                    st.adj = true;
+                    st.Padj = make_act(b, k * k * Cout, false, B * IH * IH, KU, es);
+                    st.ldadj = (int)rup(k * k * Cout, KU);
+                    st.Wadj = b.take(rup(Cin, kRowAlign) * (size_t)st.ldadj * es);
                 }
                 if (thin) {
                     st.thin = true;
@@ -476,6 +490,26 @@ struct Builder {
     WorkItem conv_dgrad(const ConvStage& st, const Act& dA) {          // fp32 patch gradients dP = dA . W^T
         WorkItem w = gemm_item(K_DGRAD_F32, conv_rows(st), st.d.in, K_of(st.d.out), p<void>(dA.rm), dA.ld, p<void>(st.d.W), st.d.ld);
         w.out0 = p<void>(st.dP); w.ld0 = st.lddp;
+        return w;
+    }
+    // input gradient of a transposed-conv stage through the adjoint patch matrix (ConvStage::adj)
+    GatherSeg adj_gather_seg(const ConvStage& st) {
+        GatherSeg g;
+        std::memset(&g, 0, sizeof(g));
+        const ConvGeom& f = st.g;
+        // rows = the stage's input pixels, columns = (kh', kw', co) with kh' = k-1-kh: source row oh = (ih*d + kh' - (k-1-pad))/so
+        g.g = ConvGeom{B, f.OH, f.OW, st.d.out, f.IH, f.IW, f.k, f.d, f.so, f.k - 1 - f.pad, f.OH * f.OW * st.dY.ld, st.dY.ld, 0};
+        g.src = p<void>(st.dY.rm);
+        g.P = p<void>(st.Padj.rm); g.ldp = st.Padj.ld;
+        tile_shape(B * f.IH * f.IW, f.k * f.k * st.d.out, &g.cl, &g.rpt, &g.tiles_r, &g.tiles_c);
+        return g;
+    }
+    WorkItem adj_dgrad(const ConvStage& st, const ConvStage& prev) {
+        const int rows = B * st.g.IH * st.g.IW, KA = st.g.k * st.g.k * st.d.out;
+        WorkItem w = gemm_item(K_DGRAD_HIDDEN, rows, st.g.Cin, K_of(KA), p<void>(st.Padj.rm), st.Padj.ld, p<void>(st.Wadj), st.ldadj);
+        w.act = prev.act;
+        w.aux0 = p<void>(prev.Y.rm); w.ldx = prev.Y.ld;
+        w.out0 = p<void>(prev.dY.rm); w.ld0 = prev.dY.ld;
         return w;
     }
     // the one-output-channel stage as direct kernels: `prev` produced its input
@@ -760,6 +794,7 @@ void build_training_plan(avae_handle* h) {
         L.blocks = base;
         if (base > 0) dst.push_back(L);
     };
+    auto is_adj = [&](int i) { bool t = false; for (const Mod& md : h->mods) t = t || (md.conv && i >= 0 && i <= 3 && md.cdec[i].adj); return t; };
     auto is_thin = [&](int i) { bool t = false; for (const Mod& md : h->mods) t = t || (md.conv && md.cdec[i].thin); return t; };
     bool any_conv = false;
     for (const Mod& md : h->mods) any_conv = any_conv || md.conv;
@@ -802,6 +837,19 @@ void build_training_plan(avae_handle* h) {
     // ---- backward: the dgrad chain (one launch per layer, all modalities), then EVERY weight gradient in the last
     // launch(es), then k_adam.  Conv stages go GEMM (fp32 patch gradients) -> k_col2im (sum + act' -> gradient of the
     // producing stage).
+    if (any_conv) {   // adjoint filter shadows of the transposed-conv stages whose input gradient goes through Padj
+        Launch L;
+        L.name = "conv_wadj"; L.type = 6;
+        int base = 0;
+        for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {
+            WadjSeg& g = L.wa.seg[L.wa.n_seg++];
+            g.Wt = h->at<void>(st.d.Wt); g.Wadj = h->at<void>(st.Wadj); g.ldt = st.d.ldt; g.ldadj = st.ldadj;
+            g.k = st.g.k; g.Cin = st.g.Cin; g.Cout = st.d.out;
+            g.block_base = base; base += (st.g.Cin * st.g.k * st.g.k * st.d.out + kThreads - 1) / kThreads;
+        }
+        L.blocks = base;
+        if (base > 0) h->bwd.push_back(L);
+    }
     group("bwd_out", h->bwd, [&] {
         for (Mod& md : h->mods) {
             if (md.conv) h->items.push_back(bd.conv_dgrad(md.cdec[4], md.dO));
@@ -811,10 +859,24 @@ void build_training_plan(avae_handle* h) {
     if (any_conv) {
         for (int i = 4; i >= 1; --i) {       // stage i's patch gradients -> dY of stage i-1; then stage i-1's dgrad GEMM
             // (a direct stage has no patch gradients: its k_thin launch wrote the producing stage's gradient itself)
-            if (!(i <= 3 && is_thin(i)))
+            if (!(i <= 3 && is_thin(i)) && !is_adj(i))
                 col2im_launch("conv_dec" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
                               [&](Mod& md) -> const ConvStage* { return &md.cdec[i - 1]; });
             if (i - 1 <= 3 && is_thin(i - 1)) { thin_launch("conv_bwd_dec" + std::to_string(i) + "_direct", h->bwd, 1); continue; }
+            if (is_adj(i - 1)) {     // patch matrix of stage i-1's output gradient -> GEMM with the adjoint filter -> dY of stage i-2
+                Launch L;
+                L.name = "conv_bwd_dec" + std::to_string(i) + "_im2col"; L.type = 1;
+                int base = 0;
+                for (Mod& md : h->mods) if (md.conv) {
+                    GatherSeg g = bd.adj_gather_seg(md.cdec[i - 1]);
+                    g.tile_base = base; base += g.tiles_r * g.tiles_c;
+                    L.ga.seg[L.ga.n_seg++] = g;
+                }
+                L.blocks = base;
+                h->bwd.push_back(L);
+                group("conv_bwd_dec" + std::to_string(i), h->bwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.adj_dgrad(md.cdec[i - 1], md.cdec[i - 2])); });
+                continue;
+            }
             group("conv_bwd_dec" + std::to_string(i), h->bwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_dgrad(md.cdec[i - 1], md.cdec[i - 1].dY)); });
         }
         // first decoder stage: its input is z -> latent mode turns dz into [dmu | dlv]
@@ -1038,6 +1100,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         else if (L.type == 3) launch_reduce(L.ra, L.blocks, s);
         else if (L.type == 4) launch_thin(h->cfg.compute_dtype, L.ta, L.blocks, s);
         else if (L.type == 5) launch_colsum(L.ra, L.blocks, s);
+        else if (L.type == 6) launch_wadj(h->cfg.compute_dtype, L.wa, L.blocks, s);
         else if (L.tn) launch_grouped_tn(h->cfg.compute_dtype, L.cfg, L.targs, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to

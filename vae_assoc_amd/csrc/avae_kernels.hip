@@ -1281,6 +1281,28 @@ void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStre
     else AVAE_LAUNCH((k_col2im<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
+// ------------------------------------------------------------------ adjoint filter shadows (transposed-conv input gradients)
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_wadj(WadjArgs a) {
+    const int bid = blockIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
+    const WadjSeg& w = a.seg[it];
+    const int KA = w.k * w.k * w.Cout;
+    const int i = (bid - w.block_base) * kThreads + (int)threadIdx.x;
+    if (i >= w.Cin * KA) return;
+    const int ci = i / KA, r = i - ci * KA, kp = r / w.Cout, co = r - kp * w.Cout, kh = kp / w.k, kw = kp - kh * w.k;
+    const CT* Wt = reinterpret_cast<const CT*>(w.Wt);
+    reinterpret_cast<CT*>(w.Wadj)[(size_t)ci * w.ldadj + r] =
+        Wt[(size_t)co * w.ldt + ((w.k - 1 - kh) * w.k + (w.k - 1 - kw)) * w.Cin + ci];
+}
+
+void launch_wadj(int compute_dtype, const WadjArgs& a, int n_blocks, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_wadj<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else AVAE_LAUNCH((k_wadj<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+}
+
 // ------------------------------------------------------------------ single-output-channel transposed-conv stage, direct
 // n / q for the two strides the branch uses (1, 2) without an integer division; `ok` = divisible
 __device__ __forceinline__ int div_small(int n, int q, bool& ok) {
