@@ -217,7 +217,9 @@ struct Col2imArgs { Col2imSeg seg[kMaxMod]; int n_seg; };
 //   mode 0  forward    : Y[p] = act(bias + sum_taps X[b, ih, iw, :] . F[kh, kw, :])
 //   mode 1  input grad : dX[b, ih, iw, c] = act_in'(X) * sum_taps dY[b, oh, ow] * F[kh, kw, c]
 //   mode 2  filter grad: part[image][Kp]   (summed over images by k_colsum)
-constexpr int kThinIn = 4096, kThinOut = 1024, kThinF = 1024;   // k_thin: one image per workgroup, staged in LDS (floats)
+constexpr int kThinIn = 4096, kThinOut = 1024, kThinF = 1024;   // k_thin: one image staged in LDS (floats)
+constexpr int kThinSplit = 4;          // workgroups per image (each stages the image and takes a quarter of the outputs): one
+                                       // workgroup per CU leaves the LDS latency of these loops exposed
 struct ThinSeg {
     ConvGeom g;
     const void* X;           // stage input = stored output of the producing stage, [b*src_sb + pixel*src_sp + c]

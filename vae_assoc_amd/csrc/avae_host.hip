@@ -306,7 +306,7 @@ void plan_memory(avae_handle* h) {
                 if (thin) {
                     st.thin = true;
                     st.thin_kp = (int)rup(K + 1, 4);
-                    st.thin_blocks = B;                   // filter gradient: one workgroup per image
+                    st.thin_blocks = B * kThinSplit;      // filter-gradient partial sums: one slice per workgroup
                     st.thin_part = b.take((size_t)st.thin_blocks * st.thin_kp * 4);
                 }
                 pflat += (size_t)K * Cout + (flat == 0 ? 0 : Cout);
@@ -788,7 +788,7 @@ void build_training_plan(avae_handle* h) {
         for (Mod& md : h->mods) if (md.conv && md.cdec[3].thin) {
             ThinSeg t = bd.thin_seg(md.cdec[3], md.cdec[2]);
             t.block_base = base;
-            base += h->B;                                  // one workgroup per image in every mode
+            base += h->B * kThinSplit;                     // kThinSplit workgroups per image in every mode
             L.ta.seg[L.ta.n_seg++] = t;
         }
         L.blocks = base;

@@ -1334,7 +1334,7 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
     for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
     const ThinSeg& w = a.seg[it];
     const ConvGeom g = w.g;
-    const int b = bid - w.block_base;                     // image
+    const int b = (bid - w.block_base) / kThinSplit, sub = (bid - w.block_base) % kThinSplit;     // image, share of its outputs
     const CT* X = reinterpret_cast<const CT*>(w.X) + (size_t)b * g.src_sb;
     const CT* F = reinterpret_cast<const CT*>(w.Wt);
     const int K = g.k * g.k * g.Cin, Cin = g.Cin;
@@ -1366,7 +1366,8 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
     if (a.mode == 0) {
         // Y[oh, ow] = act(bias + sum over taps (kh, kw) with ih = (oh*so + kh - pad)/d an integer in [0, IH) (same for w))
         CT* Y = reinterpret_cast<CT*>(w.Y) + (size_t)b * npo * w.ldy;
-        for (int p = tid; p < npo; p += kThreads) {
+        const int p_end = min(npo, (sub + 1) * ((npo + kThinSplit - 1) / kThinSplit));
+        for (int p = sub * ((npo + kThinSplit - 1) / kThinSplit) + tid; p < p_end; p += kThreads) {
             const int oh = p / g.OW, ow = p - oh * g.OW;
             const int bh = oh * g.so - g.pad, bw = ow * g.so - g.pad;
             int kh0 = max(0, -bh), kw0 = max(0, -bw);
@@ -1393,7 +1394,8 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
         // dX[ih, iw, c] = act_in'(X) * sum over taps with oh = (ih*d + pad - kh)/so an integer in [0, OH) of dY[oh, ow] * F[kh, kw, c]
         const int Q = (Cin + 3) >> 2;
         CT* dX = reinterpret_cast<CT*>(w.dX) + (size_t)b * npi * w.lddx;
-        for (int idx = tid; idx < npi * Q; idx += kThreads) {
+        const int per = (npi * Q + kThinSplit - 1) / kThinSplit, i_end = min(npi * Q, (sub + 1) * per);
+        for (int idx = sub * per + tid; idx < i_end; idx += kThreads) {
             const int pix = idx / Q, c0 = (idx - pix * Q) * 4;
             const int ih = pix / g.IW, iw = pix - ih * g.IW;
             const int th = ih * g.d + g.pad, tw = iw * g.d + g.pad;
@@ -1422,9 +1424,10 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
         // dF[kh, kw, c] = sum_{ih, iw} X[ih, iw, c] * dY[(ih*d + pad - kh)/so, (iw*d + pad - kw)/so]; thread t owns tap t (and
         // t + 256, ...); part[image][K] = bias gradient = sum of the map
         {   // bias: 64 strided partial sums, then thread 0 adds them in order
-            if (tid < 64) {
+            if (tid < 64) {                                     // this workgroup's share of the map
+                const int per = (npo + kThinSplit - 1) / kThinSplit, e = min(npo, (sub + 1) * per);
                 float sacc = 0.0f;
-                for (int i = tid; i < npo; i += 64) sacc += sdy[i];
+                for (int i = sub * per + tid; i < e; i += 64) sacc += sdy[i];
                 sred[tid] = sacc;
             }
             lds_barrier();
@@ -1433,7 +1436,8 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
             float acc = 0.0f;
             if (t < K) {
                 const int kp = t / Cin, c = t - kp * Cin, kh = kp / g.k, kw = kp - kh * g.k;
-                for (int ih = 0; ih < g.IH; ++ih) {
+                const int hper = (g.IH + kThinSplit - 1) / kThinSplit;      // this workgroup's share of the input rows
+                for (int ih = sub * hper; ih < min(g.IH, (sub + 1) * hper); ++ih) {
                     bool okh;
                     const int oh = div_small(ih * g.d + g.pad - kh, g.so, okh);
                     if (!okh || oh < 0 || oh >= g.OH) continue;
@@ -1456,7 +1460,7 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
             } else if (t == K && g.ones) {
                 for (int i = 0; i < 64; ++i) acc += sred[i];
             }
-            w.part[(size_t)b * w.Kp + t] = acc;
+            w.part[(size_t)(bid - w.block_base) * w.Kp + t] = acc;
         }
     }
 }
