@@ -204,6 +204,8 @@ struct Col2imSeg {
     int act;                          // AVAE_ACT_* of the producing layer
     void* dA; int lda;                // [B*IH*IW][lda]
     const float* g0; int nz;          // latent mode when g0 != nullptr
+    const void* bias; int bias_ld;    // forward mode when bias != nullptr (a transposed conv as scatter product + overlap-add):
+                                      // dA = act(sum + bias[c * bias_ld]) instead of sum * act'(yprev)
     int tiles_r, tiles_c, tile_base;
     int cl, rpt;                      // tile shape: cl (1..16, power of two) lanes of 4 columns, rpt (1 or 4) rows per thread:
                                       // (256/cl)*rpt rows x 4*cl columns -- narrow outputs get tall tiles, short ones many tiles
@@ -238,9 +240,20 @@ void launch_colsum(const ReduceArgs& a, int n_blocks, hipStream_t s);
 
 // Adjoint filter shadow of a transposed-conv stage: Wadj[ci][(kh', kw', co)] = Wt[co][((k-1-kh')*k + (k-1-kw'))*Cin + ci], the B
 // operand of the stage's input gradient computed as a GEMM on the patch matrix of its OUTPUT gradient.
-struct WadjSeg { const void* Wt; void* Wadj; int ldt, ldadj, k, Cin, Cout, block_base; };
+// ... and its transpose Wf[(kh', kw', co)][ci], the B operand of the stage's FORWARD pass as a scatter product (below).
+struct WadjSeg { const void* Wt; void* Wadj; void* Wf; int ldt, ldadj, ldf, k, Cin, Cout, block_base; };
 struct WadjArgs { WadjSeg seg[2 * kMaxMod]; int n_seg; };
 void launch_wadj(int compute_dtype, const WadjArgs& a, int n_blocks, hipStream_t s);
+// Filter gradient of such a stage, computed in the adjoint frame Gadj[ci][(kh', kw', co)] = sum_pixels X[p][ci] * Padj[p][...],
+// moved into the gradient buffer's layout G[(kh, kw, ci)][co] (kh = k-1-kh').
+struct GpermSeg { const float* Gadj; float* G; int ldga, ld, k, Cin, Cout, block_base; };
+struct GpermArgs { GpermSeg seg[2 * kMaxMod]; int n_seg; };
+void launch_gperm(const GpermArgs& a, int n_blocks, hipStream_t s);
+// Column sums of a compute-type matrix, first level: workgroup j adds rows j, j + blocks, ... -> part[j][cols4] (the bias
+// gradient of a conv stage = column sums of its output gradient; k_colsum adds the partial sums in order).
+struct RowsumSeg { const void* src; float* part; int ld, rows, cols, cols4, cpow, n_blocks, block_base; };
+struct RowsumArgs { RowsumSeg seg[2 * kMaxMod]; int n_seg; };
+void launch_rowsum(int compute_dtype, const RowsumArgs& a, int n_blocks, hipStream_t s);
 
 void launch_gather(int compute_dtype, const GatherArgs& a, int n_blocks, hipStream_t s);
 void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStream_t s);

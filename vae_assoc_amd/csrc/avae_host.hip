@@ -51,6 +51,8 @@ struct Dense {             // one dense layer, weights + bias as W_aug [(in+1)][
     bool head = false;     // [mu|sigma] fused head: flat layout is Wmu,bmu,Wsig,bsig
 };
 
+constexpr int kRowsumBlocks = 256;   // workgroups of the bias-gradient row sums (k_rowsum)
+
 struct Act {               // activation or gradient: row-major [rows p][ld] (every consumer reads it as stored)
     int width = 0;
     int rows = 0;          // logical rows (batch, or batch * output pixels for a conv stage)
@@ -78,6 +80,15 @@ struct ConvStage {
     Act Padj;              // that patch matrix, rows = B*IH*IW, width = k*k*Cout
     size_t Wadj = 0;       // adjoint filter shadow [Cin (padded)][ldadj]
     int ldadj = 0;
+    size_t Wf = 0;         // its transpose [k*k*Cout (padded)][ldf]: B operand of the forward scatter product
+    int ldf = 0;
+    size_t T = 0;          // fp32 scatter product [B*IH*IW][ldT] = X . Wadj, overlap-added into Y by k_col2im (forward mode)
+    int ldT = 0;
+    size_t Gadj = 0;       // fp32 filter gradient in the adjoint frame [Cin][ldga] (+ aksplit slices at apart)
+    int ldga = 0, aksplit = 1, akchunk = 0;
+    size_t apart = 0;
+    size_t rs_part = 0;    // bias gradient: partial column sums of dY [kRowsumBlocks][rs_cols4]
+    int rs_cols4 = 0;
     bool thin = false;     // one output channel: direct kernels (k_thin) instead of im2col -> GEMM -> col2im in the training plan
     size_t thin_part = 0;  // its filter-gradient partial sums [thin_blocks][Kp]
     int thin_blocks = 0, thin_kp = 0;
@@ -109,6 +120,8 @@ struct Launch {
     ReduceArgs ra{};
     ThinArgs ta{};
     WadjArgs wa{};
+    GpermArgs gp{};
+    RowsumArgs rs{};
 };
 
 struct TimingRec { hipEvent_t a, b; int launch_name; };
@@ -297,11 +310,29 @@ void plan_memory(avae_handle* h) {
                 // transposed convs that upsample (d > 1) or pad heavily have an OUTPUT far larger than their input: the fp32 patch
                 // gradients [B*OH*OW][k*k*Cin] of the plain path (160 MB for 7x7x32 -> 14x14x16) are replaced by the compute-type
                 // patch matrix of the output gradient, [B*IH*IW][k*k*Cout] (11 MB), times the adjoint filter
-                if (flat == 1 && plain_out && !thin && IH > 1 && (long)IH * IH * Cout < (long)OH * OH * Cin * 2 && !std::getenv("AVAE_NO_ADJ")) {
+                if (flat == 1 && plain_out && !thin && IH > 1 && Cout <= 64 && (long)IH * IH * Cout < (long)OH * OH * Cin * 2 && !std::getenv("AVAE_NO_ADJ")) {
                     st.adj = true;
                     st.Padj = make_act(b, k * k * Cout, false, B * IH * IH, KU, es);
                     st.ldadj = (int)rup(k * k * Cout, KU);
                     st.Wadj = b.take(rup(Cin, kRowAlign) * (size_t)st.ldadj * es);
+                    const int KA = k * k * Cout, rin = B * IH * IH;
+                    st.ldf = (int)rup(Cin, KU);
+                    st.Wf = b.take(rup(KA, kRowAlign) * (size_t)st.ldf * es);
+                    st.ldT = (int)rup(KA, 8);
+                    st.T = b.take((size_t)rin * st.ldT * 4);
+                    st.ldga = (int)rup(KA, 4);
+                    st.Gadj = b.take((size_t)Cin * st.ldga * 4);
+                    {   // split of the adjoint filter gradient's K range (= input pixels), as for the plain stages above
+                        const int steps = (int)(rup(rin, KU) / KU), tiles = ((Cin + 63) / 64) * ((KA + 63) / 64);
+                        const int split = std::min(steps / 8, (512 + tiles - 1) / tiles);
+                        if (split > 1) {
+                            st.akchunk = (steps + split - 1) / split;
+                            st.aksplit = (steps + st.akchunk - 1) / st.akchunk;
+                            st.apart = b.take((size_t)st.aksplit * Cin * st.ldga * 4);
+                        }
+                    }
+                    st.rs_cols4 = (int)rup(Cout, 4);
+                    st.rs_part = b.take((size_t)kRowsumBlocks * st.rs_cols4 * 4);
                 }
                 if (thin) {
                     st.thin = true;
@@ -504,6 +535,34 @@ struct Builder {
         tile_shape(B * f.IH * f.IW, f.k * f.k * st.d.out, &g.cl, &g.rpt, &g.tiles_r, &g.tiles_c);
         return g;
     }
+    // forward of such a stage: T = X . Wadj (rows = its input pixels), then overlap-add + bias + transfer function
+    WorkItem adj_fwd(const ConvStage& st, const ConvStage& prev) {
+        const int rows = B * st.g.IH * st.g.IW, KA = st.g.k * st.g.k * st.d.out;
+        WorkItem w = gemm_item(K_DGRAD_F32, rows, KA, K_of(st.g.Cin), p<void>(prev.Y.rm), prev.Y.ld, p<void>(st.Wf), st.ldf);
+        w.out0 = p<void>(st.T); w.ld0 = st.ldT;
+        return w;
+    }
+    Col2imSeg adj_overlap_seg(const ConvStage& st) {
+        Col2imSeg c;
+        std::memset(&c, 0, sizeof(c));
+        const ConvGeom& f = st.g;
+        c.g = ConvGeom{B, f.OH, f.OW, st.d.out, f.IH, f.IW, f.k, f.d, f.so, f.k - 1 - f.pad, 0, 0, 0};
+        c.dP = p<float>(st.T); c.lddp = st.ldT;
+        c.bias = p<unsigned char>(st.d.Wt) + (size_t)st.d.in * h->es; c.bias_ld = st.d.ldt;
+        c.act = st.act;
+        c.dA = p<void>(st.Y.rm); c.lda = st.Y.ld;
+        tile_shape(B * f.OH * f.OW, st.d.out, &c.cl, &c.rpt, &c.tiles_r, &c.tiles_c);
+        return c;
+    }
+    // filter gradient in the adjoint frame: Gadj[ci][(kh', kw', co)] = sum over input pixels of X[p][ci] * Padj[p][...]
+    WorkItem adj_wgrad(const ConvStage& st, const ConvStage& prev) {
+        const int rows = B * st.g.IH * st.g.IW, KA = st.g.k * st.g.k * st.d.out;
+        WorkItem w = gemm_item(K_WGRAD, st.g.Cin, KA, K_of(rows), p<void>(prev.Y.rm), prev.Y.ld, p<void>(st.Padj.rm), st.Padj.ld);
+        w.out0 = p<void>(st.Gadj); w.ld0 = st.ldga;
+        if (st.aksplit > 1) { w.ksplit = st.aksplit; w.kchunk = st.akchunk; w.out1 = p<void>(st.apart); }
+        w.bias_row = -1;
+        return w;
+    }
     WorkItem adj_dgrad(const ConvStage& st, const ConvStage& prev) {
         const int rows = B * st.g.IH * st.g.IW, KA = st.g.k * st.g.k * st.d.out;
         WorkItem w = gemm_item(K_DGRAD_HIDDEN, rows, st.g.Cin, K_of(KA), p<void>(st.Padj.rm), st.Padj.ld, p<void>(st.Wadj), st.ldadj);
@@ -662,8 +721,10 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
     for (int i = first; i < first + count; ++i) {
         WorkItem& w = items[i];
         if (is_gemm(w.kind)) {
-            w.bias_row = 0;
-            if (w.kind == K_WGRAD && w.M > 1 && (w.M - 1) % TM == 0 && !std::getenv("AVAE_NO_BIAS_MFMA")) w.bias_row = w.M - 1;
+            if (w.bias_row >= 0) {       // (< 0: a product without a bias row, e.g. the adjoint-frame filter gradients)
+                w.bias_row = 0;
+                if (w.kind == K_WGRAD && w.M > 1 && (w.M - 1) % TM == 0 && !std::getenv("AVAE_NO_BIAS_MFMA")) w.bias_row = w.M - 1;
+            }
             w.tiles_m = (w.M - (w.bias_row > 0 ? 1 : 0) + TM - 1) / TM;
             w.tiles_n = (w.N + T - 1) / T;
             if ((w.kind == K_FWD_HEAD || w.kind == K_DGRAD_LATENT) && w.tiles_n != 1) throw Err("internal error: head tile");
@@ -719,7 +780,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
                 if (n >= kMaxTnItems) throw Err("internal error: too many weight-gradient entries");
                 TnItem& t = L.targs.items[n++];
                 t.A = w.A; t.B = w.B; t.out = reinterpret_cast<float*>(w.ksplit > 1 ? w.out1 : w.out0);
-                t.bias_row = w.bias_row;
+                t.bias_row = std::max(w.bias_row, 0);
                 t.M = w.bias_row > 0 ? w.M - 1 : w.M; t.N = w.N; t.K = w.K; t.lda = w.lda; t.ldb = w.ldb; t.ld0 = w.ld0;
                 t.tiles_m = w.tiles_m; t.tiles_n = w.tiles_n; t.ksplit = w.ksplit; t.kchunk = w.kchunk;
                 t.tile_off = off; t.tile_cnt = std::min(SX, nt - off);
@@ -818,9 +879,36 @@ void build_training_plan(avae_handle* h) {
         group("fwd_dec" + std::to_string(k + 1), h->fwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k]));
         });
+    if (any_conv) {   // adjoint filter shadows of the transposed-conv stages that run through Padj / the scatter product (refreshed once per step)
+        Launch L;
+        L.name = "conv_wadj"; L.type = 6;
+        int base = 0;
+        for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {
+            WadjSeg& g = L.wa.seg[L.wa.n_seg++];
+            g.Wt = h->at<void>(st.d.Wt); g.Wadj = h->at<void>(st.Wadj); g.Wf = h->at<void>(st.Wf); g.ldt = st.d.ldt; g.ldadj = st.ldadj; g.ldf = st.ldf;
+            g.k = st.g.k; g.Cin = st.g.Cin; g.Cout = st.d.out;
+            g.block_base = base; base += (st.g.Cin * st.g.k * st.g.k * st.d.out + kThreads - 1) / kThreads;
+        }
+        L.blocks = base;
+        if (base > 0) h->fwd.push_back(L);
+    }
     if (any_conv) {   // deconv decoder: (im2col of the dilated input, GEMM + bias + sigmoid) x 4, then flatten for the dense output
         for (int i = 0; i < 4; ++i) {
             if (is_thin(i)) { thin_launch("conv_dec" + std::to_string(i + 1) + "_direct", h->fwd, 0); continue; }
+            if (is_adj(i)) {       // scatter product on the stage's (small) input, then overlap-add + bias + transfer function
+                group("conv_dec" + std::to_string(i + 1) + "_scatter", h->fwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.adj_fwd(md.cdec[i], md.cdec[i - 1])); });
+                Launch L;
+                L.name = "conv_dec" + std::to_string(i + 1) + "_overlap"; L.type = 2;
+                int base = 0;
+                for (Mod& md : h->mods) if (md.conv) {
+                    Col2imSeg c = bd.adj_overlap_seg(md.cdec[i]);
+                    c.tile_base = base; base += c.tiles_r * c.tiles_c;
+                    L.ca.seg[L.ca.n_seg++] = c;
+                }
+                L.blocks = base;
+                h->fwd.push_back(L);
+                continue;
+            }
             gather_launch("conv_dec" + std::to_string(i + 1) + "_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
                           [&](Mod& md) { return i == 0 ? h->at<void>(md.Z.rm) : h->at<void>(md.cdec[i - 1].Y.rm); });
             group("conv_dec" + std::to_string(i + 1), h->fwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_fwd(md.cdec[i])); });
@@ -837,19 +925,6 @@ void build_training_plan(avae_handle* h) {
     // ---- backward: the dgrad chain (one launch per layer, all modalities), then EVERY weight gradient in the last
     // launch(es), then k_adam.  Conv stages go GEMM (fp32 patch gradients) -> k_col2im (sum + act' -> gradient of the
     // producing stage).
-    if (any_conv) {   // adjoint filter shadows of the transposed-conv stages whose input gradient goes through Padj
-        Launch L;
-        L.name = "conv_wadj"; L.type = 6;
-        int base = 0;
-        for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {
-            WadjSeg& g = L.wa.seg[L.wa.n_seg++];
-            g.Wt = h->at<void>(st.d.Wt); g.Wadj = h->at<void>(st.Wadj); g.ldt = st.d.ldt; g.ldadj = st.ldadj;
-            g.k = st.g.k; g.Cin = st.g.Cin; g.Cout = st.d.out;
-            g.block_base = base; base += (st.g.Cin * st.g.k * st.g.k * st.d.out + kThreads - 1) / kThreads;
-        }
-        L.blocks = base;
-        if (base > 0) h->bwd.push_back(L);
-    }
     group("bwd_out", h->bwd, [&] {
         for (Mod& md : h->mods) {
             if (md.conv) h->items.push_back(bd.conv_dgrad(md.cdec[4], md.dO));
@@ -918,7 +993,11 @@ void build_training_plan(avae_handle* h) {
         for (Mod& md : h->mods) {
             if (md.conv) {
                 wg.push_back(bd.wgrad_stage(md.cdec[4], md.dO));
-                for (int i = 3; i >= 0; --i) if (!md.cdec[i].thin) wg.push_back(bd.wgrad_stage(md.cdec[i], md.cdec[i].dY));
+                for (int i = 3; i >= 0; --i) {
+                    if (md.cdec[i].thin) continue;
+                    if (md.cdec[i].adj) wg.push_back(bd.adj_wgrad(md.cdec[i], md.cdec[i - 1]));
+                    else wg.push_back(bd.wgrad_stage(md.cdec[i], md.cdec[i].dY));
+                }
                 wg.push_back(bd.wgrad_stage(md.cenc[3], md.dH));
                 for (int i = 2; i >= 0; --i) wg.push_back(bd.wgrad_stage(md.cenc[i], md.cenc[i].dY));
                 continue;
@@ -952,16 +1031,37 @@ void build_training_plan(avae_handle* h) {
                   [&] { for (const WorkItem& w : chunks[c]) h->items.push_back(w); });
         }
         thin_launch("conv_dec4_wgrad_direct", h->wgrad, 2);
+        {   // bias gradients of the adjoint-frame stages = column sums of their output gradient, first level
+            Launch L;
+            L.name = "conv_bias_rowsum"; L.type = 8;
+            int base = 0;
+            for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {
+                RowsumSeg& g = L.rs.seg[L.rs.n_seg++];
+                g.src = h->at<void>(st.dY.rm); g.part = h->at<float>(st.rs_part); g.ld = st.dY.ld;
+                g.rows = h->B * st.g.OH * st.g.OW; g.cols = st.d.out; g.cols4 = st.rs_cols4; g.n_blocks = kRowsumBlocks;
+                g.cpow = 4; while (g.cpow < g.cols4) g.cpow *= 2;
+                if (g.cpow > 64) throw Err("internal error: bias row sums hold at most 64 columns");
+                g.block_base = base; base += kRowsumBlocks;
+            }
+            L.blocks = base;
+            if (base > 0) h->wgrad.push_back(L);
+        }
         {   // ... and its per-image partial sums -> the gradient buffer (one column of the padded matrix)
             Launch R;
             R.name = "conv_dec4_wgrad_sum"; R.type = 5;
             int base = 0;
+            for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {      // second level of the row sums
+                ReduceSeg& g = R.ra.seg[R.ra.n_seg++];
+                g.dst = h->grad() + st.d.master + (size_t)st.d.in * st.d.ld; g.src = h->at<float>(st.rs_part);
+                g.n = st.d.out; g.parts = kRowsumBlocks; g.stride = st.rs_cols4; g.dst_ld = 1;
+                g.block_base = base; base += (g.n + 3) / 4;
+            }
             for (Mod& md : h->mods) if (md.conv && md.cdec[3].thin) {
                 const ConvStage& st = md.cdec[3];
                 ReduceSeg& g = R.ra.seg[R.ra.n_seg++];
                 g.dst = h->grad() + st.d.master; g.src = h->at<float>(st.thin_part);
                 g.n = st.d.in + 1; g.parts = st.thin_blocks; g.stride = st.thin_kp; g.dst_ld = st.d.ld;
-                g.block_base = base; base += (g.n + 15) / 16;
+                g.block_base = base; base += (g.n + 3) / 4;
             }
             R.blocks = base;
             if (base > 0) h->wgrad.push_back(R);
@@ -979,6 +1079,19 @@ void build_training_plan(avae_handle* h) {
             }
             R.blocks = base;
             if (base > 0) h->wgrad.push_back(R);
+        }
+        {   // adjoint-frame filter gradients -> the gradient buffer's layout
+            Launch L;
+            L.name = "conv_wgrad_perm"; L.type = 7;
+            int base = 0;
+            for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {
+                GpermSeg& g = L.gp.seg[L.gp.n_seg++];
+                g.Gadj = h->at<float>(st.Gadj); g.G = h->grad() + st.d.master; g.ldga = st.ldga; g.ld = st.d.ld;
+                g.k = st.g.k; g.Cin = st.g.Cin; g.Cout = st.d.out;
+                g.block_base = base; base += (st.g.Cin * st.g.k * st.g.k * st.d.out + kThreads - 1) / kThreads;
+            }
+            L.blocks = base;
+            if (base > 0) h->wgrad.push_back(L);
         }
     }
     // ---- eval: forward launches + a lone cost reduction that does not bump the step
@@ -1101,6 +1214,8 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         else if (L.type == 4) launch_thin(h->cfg.compute_dtype, L.ta, L.blocks, s);
         else if (L.type == 5) launch_colsum(L.ra, L.blocks, s);
         else if (L.type == 6) launch_wadj(h->cfg.compute_dtype, L.wa, L.blocks, s);
+        else if (L.type == 7) launch_gperm(L.gp, L.blocks, s);
+        else if (L.type == 8) launch_rowsum(h->cfg.compute_dtype, L.rs, L.blocks, s);
         else if (L.tn) launch_grouped_tn(h->cfg.compute_dtype, L.cfg, L.targs, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to

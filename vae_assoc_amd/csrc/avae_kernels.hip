@@ -1222,7 +1222,11 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
                         for (int e = 0; e < 4; ++e) acc[e] += t[e];
                     }
                 }
-                if (latent) {        // dmu = dz + g0mu ; dlv = dz * F + g0lv   (g0 = [g0mu | g0lv | F], reparameterisation)
+                if (w.bias) {        // forward mode: overlap-add of a scatter product, + bias, transfer function
+                    const CT* bs = reinterpret_cast<const CT*>(w.bias);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = act_fwd(w.act, acc[e] + ct_load<CT>(bs + (size_t)(ci0 + e) * w.bias_ld));
+                } else if (latent) { // dmu = dz + g0mu ; dlv = dz * F + g0lv   (g0 = [g0mu | g0lv | F], reparameterisation)
                     const int lde = (w.nz + 3) & ~3;
                     const float* gr = w.g0 + (size_t)pix * 3 * lde;
 #pragma unroll
@@ -1249,7 +1253,9 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
                         acc += w.dP[(size_t)((b * g.OH + oh) * g.OW + ow) * w.lddp + (kh * g.k + kw) * g.Cin + ci];
                     }
                 }
-                if (latent) {        // dmu = dz + g0mu ; dlv = dz * F + g0lv   (g0 = [g0mu | g0lv | F], reparameterisation)
+                if (w.bias) {
+                    acc = act_fwd(w.act, acc + ct_load<CT>(reinterpret_cast<const CT*>(w.bias) + (size_t)ci * w.bias_ld));
+                } else if (latent) { // dmu = dz + g0mu ; dlv = dz * F + g0lv   (g0 = [g0mu | g0lv | F], reparameterisation)
                     const int lde = (w.nz + 3) & ~3;                      // g0 row = [g0mu | g0lv | F], each roundup(n_z, 4) wide
                     const float* gr = w.g0 + (size_t)pix * 3 * lde;
                     acc = col < w.nz ? acc + gr[ci] : acc * gr[2 * lde + ci] + gr[lde + ci];
@@ -1293,8 +1299,65 @@ __global__ void __launch_bounds__(kThreads) k_wadj(WadjArgs a) {
     if (i >= w.Cin * KA) return;
     const int ci = i / KA, r = i - ci * KA, kp = r / w.Cout, co = r - kp * w.Cout, kh = kp / w.k, kw = kp - kh * w.k;
     const CT* Wt = reinterpret_cast<const CT*>(w.Wt);
-    reinterpret_cast<CT*>(w.Wadj)[(size_t)ci * w.ldadj + r] =
-        Wt[(size_t)co * w.ldt + ((w.k - 1 - kh) * w.k + (w.k - 1 - kw)) * w.Cin + ci];
+    const CT v = Wt[(size_t)co * w.ldt + ((w.k - 1 - kh) * w.k + (w.k - 1 - kw)) * w.Cin + ci];
+    reinterpret_cast<CT*>(w.Wadj)[(size_t)ci * w.ldadj + r] = v;
+    reinterpret_cast<CT*>(w.Wf)[(size_t)r * w.ldf + ci] = v;
+}
+
+__global__ void __launch_bounds__(kThreads) k_gperm(GpermArgs a) {
+    const int bid = blockIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
+    const GpermSeg& w = a.seg[it];
+    const int KA = w.k * w.k * w.Cout;
+    const int i = (bid - w.block_base) * kThreads + (int)threadIdx.x;
+    if (i >= w.Cin * KA) return;
+    const int ci = i / KA, r = i - ci * KA, kp = r / w.Cout, co = r - kp * w.Cout, kh = kp / w.k, kw = kp - kh * w.k;
+    w.G[(size_t)(((w.k - 1 - kh) * w.k + (w.k - 1 - kw)) * w.Cin + ci) * w.ld + co] = w.Gadj[(size_t)ci * w.ldga + r];
+}
+
+void launch_gperm(const GpermArgs& a, int n_blocks, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    AVAE_LAUNCH(k_gperm, dim3(n_blocks), dim3(kThreads), 0, s, a);
+}
+
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_rowsum(RowsumArgs a) {
+    __shared__ float red[kThreads];
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
+    const RowsumSeg& w = a.seg[it];
+    const int j = bid - w.block_base;
+    // lanes: column c = tid % cp (cp = the power of two >= cols, <= 64), row group q = tid / cp of nq = 256 / cp;
+    // rows j + n_blocks * (q + nq * m), four loads in flight
+    const int cp = w.cpow, nq = kThreads / cp;
+    const int c = tid & (cp - 1), q = tid / cp;
+    const CT* src = reinterpret_cast<const CT*>(w.src);
+    float acc = 0.0f;
+    if (c < w.cols) {
+        const int step = w.n_blocks * nq;
+        for (int r = j + w.n_blocks * q; r < w.rows; r += 4 * step) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = r + u * step < w.rows ? ct_load<CT>(src + (size_t)(r + u * step) * w.ld + c) : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+        }
+    }
+    red[tid] = acc;
+    lds_barrier();
+    if (q == 0 && c < w.cols4) {
+        float t = 0.0f;
+        for (int k = 0; k < nq; ++k) t += red[k * cp + c];
+        w.part[(size_t)j * w.cols4 + c] = c < w.cols ? t : 0.0f;
+    }
+}
+
+void launch_rowsum(int compute_dtype, const RowsumArgs& a, int n_blocks, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_rowsum<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else AVAE_LAUNCH((k_rowsum<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
 void launch_wadj(int compute_dtype, const WadjArgs& a, int n_blocks, hipStream_t s) {
@@ -1465,33 +1528,32 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
     }
 }
 
-// Column sums of the direct stage's per-image partial filter gradients: dst[i*dst_ld] = sum_s src[s*stride + i].  16 lanes of
-// a workgroup share an element, lane group q adding slices q, q+16, ... in order; the 16 group sums are then added in
-// order: a fixed tree, reproducible.
+// Column sums of per-workgroup partial sums (the direct stage's filter gradient, the bias row sums):
+// dst[i*dst_ld] = sum_s src[s*stride + i].  A workgroup takes 4 elements; lane group q of 64 adds slices q, q+64, ... in order,
+// then the 64 group sums are added in order: a fixed tree, reproducible.
 __global__ void __launch_bounds__(kThreads) k_colsum(ReduceArgs a) {
-    __shared__ float red[16][17];
+    __shared__ float red[64][5];
     const int bid = blockIdx.x, tid = threadIdx.x;
     int it = 0;
     for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
     const ReduceSeg& g = a.seg[it];
-    const int e = tid & 15, q = tid >> 4;
-    const int i = (bid - g.block_base) * 16 + e;
+    const int e = tid & 3, q = tid >> 2;
+    const int i = (bid - g.block_base) * 4 + e;
     float acc = 0.0f;
     if (i < g.n) {
-        for (int s0 = q; s0 < g.parts; s0 += 16 * 4) {
+        for (int s0 = q; s0 < g.parts; s0 += 64 * 4) {
             float v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = g.src[(size_t)min(s0 + 16 * u, g.parts - 1) * g.stride + i];
+            for (int u = 0; u < 4; ++u) v[u] = g.src[(size_t)min(s0 + 64 * u, g.parts - 1) * g.stride + i];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (s0 + 16 * u < g.parts) acc += v[u];
+            for (int u = 0; u < 4; ++u) if (s0 + 64 * u < g.parts) acc += v[u];
         }
     }
     red[q][e] = acc;
     lds_barrier();
     if (q == 0 && i < g.n) {
         float t = red[0][e];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) t += red[k][e];
+        for (int k = 1; k < 64; ++k) t += red[k][e];
         g.dst[(size_t)i * (g.dst_ld > 0 ? g.dst_ld : 1)] = t;
     }
 }
