@@ -274,6 +274,17 @@ def test_conv_only_model(V, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_two_conv_modalities_mixed_paths(V, dtype):
+    """Two conv modalities in one model (every conv helper launch carries two segments) with depths that take
+    different routes: generator depths 144/8 give a 72-channel transposed conv (patch-matrix path: more than 64
+    output channels) next to adjoint-frame and direct one-channel stages; 20/12 keeps channel counts that are
+    not multiples of 4 on one stage (scalar gather paths) and multiples on the others."""
+    a = dict(make_arch("img_a", 784, 8, 24, 5), hidden_conv=True, n_hidden_gener_1=144, n_hidden_gener_2=8)
+    b = dict(make_arch("img_b", 784, 4, 16, 5), hidden_conv=True, n_hidden_gener_1=20, n_hidden_gener_2=12)
+    check_step_parity(V, [a, b], [True, True], [2.0, 1.0], 0.5, "relu", 12, dtype, steps=2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_large_tile_path(V, dtype):
     """Wide layers and a large batch select the 128x128 tile configuration.  softplus, not relu:
     with 2048 x 384 hidden units some pre-activation lands within fp32 rounding of the relu kink and

@@ -815,11 +815,13 @@ void build_training_plan(avae_handle* h) {
         dst.push_back(finish_launch(h, h->items, first, count, name, &slot));
     };
     // conv-branch helper launches (one segment per conv modality)
-    auto gather_launch = [&](const std::string& name, std::vector<Launch>& dst, auto&& stage_of, auto&& src_of) {
+    // (`want`: which conv modalities take part -- stages route per modality: patch-matrix, adjoint-frame or direct)
+    auto every_conv = [](const Mod&) { return true; };
+    auto gather_launch = [&](const std::string& name, std::vector<Launch>& dst, auto&& stage_of, auto&& src_of, auto&& want) {
         Launch L;
         L.name = name; L.type = 1;
         int base = 0;
-        for (Mod& md : h->mods) if (md.conv) {
+        for (Mod& md : h->mods) if (md.conv && want(md)) {
             GatherSeg g = bd.gather_seg(stage_of(md), src_of(md));
             g.tile_base = base; base += g.tiles_r * g.tiles_c;
             L.ga.seg[L.ga.n_seg++] = g;
@@ -827,11 +829,11 @@ void build_training_plan(avae_handle* h) {
         L.blocks = base;
         if (base > 0) dst.push_back(L);
     };
-    auto col2im_launch = [&](const std::string& name, std::vector<Launch>& dst, auto&& stage_of, auto&& prev_of) {
+    auto col2im_launch = [&](const std::string& name, std::vector<Launch>& dst, auto&& stage_of, auto&& prev_of, auto&& want) {
         Launch L;
         L.name = name; L.type = 2;
         int base = 0;
-        for (Mod& md : h->mods) if (md.conv) {
+        for (Mod& md : h->mods) if (md.conv && want(md)) {
             Col2imSeg c = bd.col2im_seg(stage_of(md), prev_of(md), md);
             c.tile_base = base; base += c.tiles_r * c.tiles_c;
             L.ca.seg[L.ca.n_seg++] = c;
@@ -868,11 +870,11 @@ void build_training_plan(avae_handle* h) {
     if (any_conv) {   // conv encoder: (im2col, GEMM) x 3, then the patch matrix of the flatten+dense heads
         for (int i = 0; i < 3; ++i) {
             gather_launch("conv_enc" + std::to_string(i + 1) + "_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cenc[i]; },
-                          [&](Mod& md) { return i == 0 ? h->at<void>(md.X0.rm) : h->at<void>(md.cenc[i - 1].Y.rm); });
+                          [&](Mod& md) { return i == 0 ? h->at<void>(md.X0.rm) : h->at<void>(md.cenc[i - 1].Y.rm); }, every_conv);
             group("conv_enc" + std::to_string(i + 1), h->fwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_fwd(md.cenc[i])); });
         }
         gather_launch("conv_head_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cenc[3]; },
-                      [&](Mod& md) { return h->at<void>(md.cenc[2].Y.rm); });
+                      [&](Mod& md) { return h->at<void>(md.cenc[2].Y.rm); }, every_conv);
     }
     group("fwd_head", h->fwd, [&] { for (Mod& md : h->mods) h->items.push_back(bd.fwd_head(md, true)); });
     for (int k = 0; k < std::max(Lmax, 1); ++k)
@@ -894,27 +896,29 @@ void build_training_plan(avae_handle* h) {
     }
     if (any_conv) {   // deconv decoder: (im2col of the dilated input, GEMM + bias + sigmoid) x 4, then flatten for the dense output
         for (int i = 0; i < 4; ++i) {
-            if (is_thin(i)) { thin_launch("conv_dec" + std::to_string(i + 1) + "_direct", h->fwd, 0); continue; }
+            // every modality routes its stage i on its own (depths differ between modalities): direct, adjoint frame or patch matrix
+            auto plain = [&](const Mod& md) { return !md.cdec[i].thin && !md.cdec[i].adj; };
+            if (is_thin(i)) thin_launch("conv_dec" + std::to_string(i + 1) + "_direct", h->fwd, 0);
             if (is_adj(i)) {       // scatter product on the stage's (small) input, then overlap-add + bias + transfer function
-                group("conv_dec" + std::to_string(i + 1) + "_scatter", h->fwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.adj_fwd(md.cdec[i], md.cdec[i - 1])); });
+                group("conv_dec" + std::to_string(i + 1) + "_scatter", h->fwd, [&] {
+                    for (Mod& md : h->mods) if (md.conv && md.cdec[i].adj) h->items.push_back(bd.adj_fwd(md.cdec[i], md.cdec[i - 1])); });
                 Launch L;
                 L.name = "conv_dec" + std::to_string(i + 1) + "_overlap"; L.type = 2;
                 int base = 0;
-                for (Mod& md : h->mods) if (md.conv) {
+                for (Mod& md : h->mods) if (md.conv && md.cdec[i].adj) {
                     Col2imSeg c = bd.adj_overlap_seg(md.cdec[i]);
                     c.tile_base = base; base += c.tiles_r * c.tiles_c;
                     L.ca.seg[L.ca.n_seg++] = c;
                 }
                 L.blocks = base;
                 h->fwd.push_back(L);
-                continue;
             }
             gather_launch("conv_dec" + std::to_string(i + 1) + "_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
-                          [&](Mod& md) { return i == 0 ? h->at<void>(md.Z.rm) : h->at<void>(md.cdec[i - 1].Y.rm); });
-            group("conv_dec" + std::to_string(i + 1), h->fwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_fwd(md.cdec[i])); });
+                          [&](Mod& md) { return i == 0 ? h->at<void>(md.Z.rm) : h->at<void>(md.cdec[i - 1].Y.rm); }, plain);
+            group("conv_dec" + std::to_string(i + 1), h->fwd, [&] { for (Mod& md : h->mods) if (md.conv && plain(md)) h->items.push_back(bd.conv_fwd(md.cdec[i])); });
         }
         gather_launch("conv_out_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cdec[4]; },
-                      [&](Mod& md) { return h->at<void>(md.cdec[3].Y.rm); });
+                      [&](Mod& md) { return h->at<void>(md.cdec[3].Y.rm); }, every_conv);
     }
     group("fwd_out_loss", h->fwd, [&] {
         for (int m = 0; m < h->M; ++m) h->items.push_back(bd.fwd_out(h->mods[m], m, true));
@@ -933,30 +937,33 @@ void build_training_plan(avae_handle* h) {
     });
     if (any_conv) {
         for (int i = 4; i >= 1; --i) {       // stage i's patch gradients -> dY of stage i-1; then stage i-1's dgrad GEMM
-            // (a direct stage has no patch gradients: its k_thin launch wrote the producing stage's gradient itself)
-            if (!(i <= 3 && is_thin(i)) && !is_adj(i))
-                col2im_launch("conv_dec" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
-                              [&](Mod& md) -> const ConvStage* { return &md.cdec[i - 1]; });
-            if (i - 1 <= 3 && is_thin(i - 1)) { thin_launch("conv_bwd_dec" + std::to_string(i) + "_direct", h->bwd, 1); continue; }
+            // (per modality; a direct or adjoint-frame stage has no patch gradients: its own launches wrote the producing
+            // stage's gradient)
+            auto plain_i = [&](const Mod& md) { return !md.cdec[i].thin && !md.cdec[i].adj; };
+            auto plain_j = [&](const Mod& md) { return !md.cdec[i - 1].thin && !md.cdec[i - 1].adj; };
+            col2im_launch("conv_dec" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
+                          [&](Mod& md) -> const ConvStage* { return &md.cdec[i - 1]; }, plain_i);
+            if (is_thin(i - 1)) thin_launch("conv_bwd_dec" + std::to_string(i) + "_direct", h->bwd, 1);
             if (is_adj(i - 1)) {     // patch matrix of stage i-1's output gradient -> GEMM with the adjoint filter -> dY of stage i-2
                 Launch L;
-                L.name = "conv_bwd_dec" + std::to_string(i) + "_im2col"; L.type = 1;
+                L.name = "conv_bwd_dec" + std::to_string(i) + "_adj_im2col"; L.type = 1;
                 int base = 0;
-                for (Mod& md : h->mods) if (md.conv) {
+                for (Mod& md : h->mods) if (md.conv && md.cdec[i - 1].adj) {
                     GatherSeg g = bd.adj_gather_seg(md.cdec[i - 1]);
                     g.tile_base = base; base += g.tiles_r * g.tiles_c;
                     L.ga.seg[L.ga.n_seg++] = g;
                 }
                 L.blocks = base;
                 h->bwd.push_back(L);
-                group("conv_bwd_dec" + std::to_string(i), h->bwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.adj_dgrad(md.cdec[i - 1], md.cdec[i - 2])); });
-                continue;
+                group("conv_bwd_dec" + std::to_string(i) + "_adj", h->bwd, [&] {
+                    for (Mod& md : h->mods) if (md.conv && md.cdec[i - 1].adj) h->items.push_back(bd.adj_dgrad(md.cdec[i - 1], md.cdec[i - 2])); });
             }
-            group("conv_bwd_dec" + std::to_string(i), h->bwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_dgrad(md.cdec[i - 1], md.cdec[i - 1].dY)); });
+            group("conv_bwd_dec" + std::to_string(i), h->bwd, [&] {
+                for (Mod& md : h->mods) if (md.conv && plain_j(md)) h->items.push_back(bd.conv_dgrad(md.cdec[i - 1], md.cdec[i - 1].dY)); });
         }
         // first decoder stage: its input is z -> latent mode turns dz into [dmu | dlv]
         col2im_launch("conv_dec1_latent", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[0]; },
-                      [&](Mod&) -> const ConvStage* { return nullptr; });
+                      [&](Mod&) -> const ConvStage* { return nullptr; }, every_conv);
     }
     for (int k = Lmax - 1; k >= 1; --k)
         group("bwd_dec" + std::to_string(k + 1), h->bwd, [&] {
@@ -975,7 +982,7 @@ void build_training_plan(avae_handle* h) {
     if (any_conv) {
         for (int i = 3; i >= 1; --i) {
             col2im_launch("conv_enc" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cenc[i]; },
-                          [&](Mod& md) -> const ConvStage* { return &md.cenc[i - 1]; });
+                          [&](Mod& md) -> const ConvStage* { return &md.cenc[i - 1]; }, every_conv);
             if (i >= 2) group("conv_bwd_enc" + std::to_string(i), h->bwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_dgrad(md.cenc[i - 1], md.cenc[i - 1].dY)); });
         }
     }
