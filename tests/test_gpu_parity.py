@@ -267,6 +267,15 @@ def test_conv_deconv_branch(V, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv_branch_at_bench_size(V, dtype):
+    """`bench.py --config c2conv` (depths 16/64, 64/16; batch 256): at this size the decoder's stages take the direct
+    (one output channel) and adjoint-frame routes with split reductions over 256 images x 49..784 pixels."""
+    img = dict(make_arch("image", 784, 16, 64, 20), hidden_conv=True, n_hidden_gener_1=64, n_hidden_gener_2=16)
+    jnt = make_arch("joint", 147, 200, 200, 20)
+    check_step_parity(V, [img, jnt], [True, False], [50.0, 1.0], 8.0, "relu", 256, dtype, steps=1)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_conv_only_model(V, dtype):
     """A single conv modality (no MLP modality at all, no association term)."""
     img = dict(make_arch("image", 784, 8, 12, 6), hidden_conv=True, n_hidden_gener_1=12, n_hidden_gener_2=6)
