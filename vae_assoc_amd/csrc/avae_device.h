@@ -173,7 +173,7 @@ struct PrepArgs {
 // Fixed-order sum of the split-K slices of a weight gradient: dst[i] = sum_s src[s*stride + i]  (no atomics: reproducible).
 struct ReduceSeg { float* dst; const float* src; int n, parts; long long stride; int block_base;
                    int dst_ld; };   // dst_ld > 0: element i goes to dst[i * dst_ld] (a one-column gradient in a padded matrix)
-constexpr int kMaxReduceSegs = 24;
+constexpr int kMaxReduceSegs = 40;          // up to 9 split conv stages per modality x 4 modalities (+ bias sums)
 struct ReduceArgs { ReduceSeg seg[kMaxReduceSegs]; int n_seg; };
 
 // Conv / transposed-conv layers (reference vae_assoc.py:169-199,249-278, deconv.py:107) run on the
