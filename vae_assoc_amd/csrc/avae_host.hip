@@ -287,13 +287,15 @@ void plan_memory(avae_handle* h) {
                 const int K = k * k * Cin, rows = B * OH * OH;
                 st.d = make_dense(b, pint, K, Cout, KU, es, flat == 3);
                 st.P = make_act(b, K, bias, rows, KU, es);
-                const bool thin = Cout == 1 && plain_out && IH * IH * Cin <= kThinIn && OH * OH <= kThinOut && K + 1 <= kThinF &&
+                const bool thin = Cout == 1 && plain_out && flat == 1 && IH > 1 && IH * IH * Cin <= kThinIn && OH * OH <= kThinOut && K + 1 <= kThinF &&
                                   !std::getenv("AVAE_NO_THIN");
                 if (plain_out) {     // hidden conv stage: own output / gradient buffers
                     // (the direct stage's one-channel maps are read and written pixel by pixel, never as a GEMM operand: 8
                     // elements per pixel instead of a K-padded row of 64 keep them 8x smaller -- 3 MB instead of 26 MB)
-                    st.Y = make_act(b, Cout, false, rows, KU, es, thin ? 8 : 0);
-                    st.dY = make_act(b, Cout, false, rows, KU, es, thin ? 8 : 0);
+                    // -- only for the LAST map (28x28), whose consumer is the flatten gather; an earlier one-channel stage feeds a GEMM
+                    const int compact = thin && OH == 28 ? 8 : 0;
+                    st.Y = make_act(b, Cout, false, rows, KU, es, compact);
+                    st.dY = make_act(b, Cout, false, rows, KU, es, compact);
                 }
                 st.lddp = (int)rup(K, 8);
                 st.dP = b.take((size_t)rows * st.lddp * 4);
@@ -843,13 +845,13 @@ void build_training_plan(avae_handle* h) {
     };
     // the decoder's last transposed conv (one output channel) runs as direct kernels: mode 0 forward, 1 input gradient,
     // 2 filter-gradient partial sums
-    auto thin_launch = [&](const std::string& name, std::vector<Launch>& dst, int mode) {
+    auto thin_launch = [&](const std::string& name, std::vector<Launch>& dst, int mode, int i) {
         Launch L;
         L.name = name; L.type = 4;
         L.ta.mode = mode;
         int base = 0;
-        for (Mod& md : h->mods) if (md.conv && md.cdec[3].thin) {
-            ThinSeg t = bd.thin_seg(md.cdec[3], md.cdec[2]);
+        for (Mod& md : h->mods) if (md.conv && md.cdec[i].thin) {
+            ThinSeg t = bd.thin_seg(md.cdec[i], md.cdec[i - 1]);
             t.block_base = base;
             base += h->B * kThinSplit;                     // kThinSplit workgroups per image in every mode
             L.ta.seg[L.ta.n_seg++] = t;
@@ -898,7 +900,7 @@ void build_training_plan(avae_handle* h) {
         for (int i = 0; i < 4; ++i) {
             // every modality routes its stage i on its own (depths differ between modalities): direct, adjoint frame or patch matrix
             auto plain = [&](const Mod& md) { return !md.cdec[i].thin && !md.cdec[i].adj; };
-            if (is_thin(i)) thin_launch("conv_dec" + std::to_string(i + 1) + "_direct", h->fwd, 0);
+            if (is_thin(i)) thin_launch("conv_dec" + std::to_string(i + 1) + "_direct", h->fwd, 0, i);
             if (is_adj(i)) {       // scatter product on the stage's (small) input, then overlap-add + bias + transfer function
                 group("conv_dec" + std::to_string(i + 1) + "_scatter", h->fwd, [&] {
                     for (Mod& md : h->mods) if (md.conv && md.cdec[i].adj) h->items.push_back(bd.adj_fwd(md.cdec[i], md.cdec[i - 1])); });
@@ -943,7 +945,7 @@ void build_training_plan(avae_handle* h) {
             auto plain_j = [&](const Mod& md) { return !md.cdec[i - 1].thin && !md.cdec[i - 1].adj; };
             col2im_launch("conv_dec" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
                           [&](Mod& md) -> const ConvStage* { return &md.cdec[i - 1]; }, plain_i);
-            if (is_thin(i - 1)) thin_launch("conv_bwd_dec" + std::to_string(i) + "_direct", h->bwd, 1);
+            if (is_thin(i - 1)) thin_launch("conv_bwd_dec" + std::to_string(i) + "_direct", h->bwd, 1, i - 1);
             if (is_adj(i - 1)) {     // patch matrix of stage i-1's output gradient -> GEMM with the adjoint filter -> dY of stage i-2
                 Launch L;
                 L.name = "conv_bwd_dec" + std::to_string(i) + "_adj_im2col"; L.type = 1;
@@ -1037,7 +1039,7 @@ void build_training_plan(avae_handle* h) {
             group("wgrad" + (chunks.size() > 1 ? std::to_string(c + 1) : std::string()), h->wgrad,
                   [&] { for (const WorkItem& w : chunks[c]) h->items.push_back(w); });
         }
-        thin_launch("conv_dec4_wgrad_direct", h->wgrad, 2);
+        for (int i = 1; i <= 3; ++i) if (is_thin(i)) thin_launch("conv_dec" + std::to_string(i + 1) + "_wgrad_direct", h->wgrad, 2, i);
         {   // bias gradients of the adjoint-frame stages = column sums of their output gradient, first level
             Launch L;
             L.name = "conv_bias_rowsum"; L.type = 8;
@@ -1055,7 +1057,7 @@ void build_training_plan(avae_handle* h) {
         }
         {   // ... and its per-image partial sums -> the gradient buffer (one column of the padded matrix)
             Launch R;
-            R.name = "conv_dec4_wgrad_sum"; R.type = 5;
+            R.name = "conv_wgrad_sums"; R.type = 5;
             int base = 0;
             for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {      // second level of the row sums
                 ReduceSeg& g = R.ra.seg[R.ra.n_seg++];
@@ -1063,8 +1065,7 @@ void build_training_plan(avae_handle* h) {
                 g.n = st.d.out; g.parts = kRowsumBlocks; g.stride = st.rs_cols4; g.dst_ld = 1;
                 g.block_base = base; base += (g.n + 3) / 4;
             }
-            for (Mod& md : h->mods) if (md.conv && md.cdec[3].thin) {
-                const ConvStage& st = md.cdec[3];
+            for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.thin) {
                 ReduceSeg& g = R.ra.seg[R.ra.n_seg++];
                 g.dst = h->grad() + st.d.master; g.src = h->at<float>(st.thin_part);
                 g.n = st.d.in + 1; g.parts = st.thin_blocks; g.stride = st.thin_kp; g.dst_ld = st.d.ld;
