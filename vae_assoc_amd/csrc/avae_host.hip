@@ -788,6 +788,39 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
                 t.tile_off = off; t.tile_cnt = std::min(SX, nt - off);
             }
         }
+        if (G > 1 && !std::getenv("AVAE_NO_TN_BALANCE")) {
+            // Entry y of a group of G runs on XCDs [ (y % G) * 8/G, ... ): its position decides WHERE its tiles run.  Layers
+            // differ in size (C4: 32, 28, 8 and 4 tiles), and in plan order two of the four XCD pairs end up with 66 tiles per
+            // XCD -- a third round of 62 us for four tiles on a 32-CU XCD (195 us; the other XCDs are done after 138).  Longest
+            // first onto the lightest position balances the positions; G = 4 or 2 by the fewest rounds that leaves.
+            std::vector<TnItem> ent(L.targs.items, L.targs.items + n);
+            std::stable_sort(ent.begin(), ent.end(), [](const TnItem& a, const TnItem& b) { return a.tile_cnt > b.tile_cnt; });
+            auto pack = [&](int g, std::vector<std::vector<TnItem>>& bins) {
+                bins.assign(g, {});
+                std::vector<long> load(g, 0);
+                const int cap = kMaxTnItems / g;
+                for (const TnItem& e : ent) {
+                    int best = -1;
+                    for (int p = 0; p < g; ++p) if ((int)bins[p].size() < cap && (best < 0 || load[p] < load[best])) best = p;
+                    bins[best].push_back(e); load[best] += e.tile_cnt;
+                }
+                const long per_xcd = (*std::max_element(load.begin(), load.end()) * g + 7) / 8;
+                return (per_xcd + 31) / 32;                       // rounds on a 32-CU XCD at one workgroup per CU
+            };
+            std::vector<std::vector<TnItem>> bins, bins2;
+            if (!std::getenv("AVAE_TN_G") && G == 4 && n * 2 <= kMaxTnItems * 2) {
+                const long r4 = pack(4, bins), r2 = pack(2, bins2);
+                if (r2 < r4) { G = 2; bins.swap(bins2); }
+            } else {
+                pack(G, bins);
+            }
+            size_t groups = 0;
+            for (const auto& bn : bins) groups = std::max(groups, bn.size());
+            std::memset(L.targs.items, 0, sizeof(L.targs.items));
+            for (size_t g = 0; g < groups; ++g)
+                for (int p = 0; p < G; ++p) if (g < bins[p].size()) L.targs.items[g * G + p] = bins[p][g];      // holes: tile_cnt 0
+            n = (int)groups * G;
+        }
         L.grid_x = SX;
         L.targs.n_items = n;
         L.targs.grid_x = L.grid_x;
