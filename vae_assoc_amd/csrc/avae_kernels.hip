@@ -250,7 +250,10 @@ __device__ __forceinline__ void tile_pass(float* Cs, OT* out, int ld0, const AT*
     constexpr int LDC = BN + 4, QC = BN / VW, NG = BM * QC;   // NG groups of VW elements in the tile
     constexpr int NQT = (NG + NT - 1) / NT;               // groups per thread (the smallest tile has fewer groups than threads)
     constexpr bool PARTIAL = NG % NT != 0;
-    constexpr int NQ = NQT < 32 / VW ? NQT : 32 / VW;     // groups handled together: <= 32 elements per array in flight
+    // groups handled together: <= 32 elements per array in flight -- 64 in the 8-wave kernel's passes with an auxiliary
+    // operand (hidden-layer dgrad: act'(Y_prev)), whose load latency is then exposed once per tile instead of twice
+    constexpr int MAXE = (HAS_AUX && NT >= 512) ? 64 : 32;
+    constexpr int NQ = NQT < MAXE / VW ? NQT : MAXE / VW;
     static_assert(NQT % NQ == 0, "tile / thread mapping");
     const int tid = threadIdx.x;
     for (int q0 = 0; q0 < NQT; q0 += NQ) {
