@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Latency / throughput of the rows-agnostic decoder (`generate`, SURVEY.md 8(f) rank 4: the CEM / GUI callers of the
+reference decode 1 live row padded to batch_size, 10-50 times per iteration; here all rollouts go in one call of any
+row count).  C2 nets; device tensors in and out (no host copies) and NumPy in / out."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import __graft_entry__ as g
+g.build()
+import bench
+from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+
+archs, B, dtype, label = bench.CONFIGS["c2"]
+model = AssocVariationalAutoEncoder(archs, transfer_fct="relu", batch_size=B, compute_dtype=dtype, seed=0, **bench.HYPER)
+rng = np.random.default_rng(0)
+for rows in (1, 64, 1024, 16384):
+    z_np = rng.standard_normal((rows, 20)).astype(np.float32)
+    z_dev = torch.as_tensor(z_np).cuda()
+    for name, z in (("device tensors", z_dev), ("numpy in/out", z_np)):
+        n = 300 if rows <= 1024 else 50
+        for _ in range(10):
+            model.generate(z)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            out = model.generate(z)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / n
+        print("rows %6d  %-15s %8.1f us/call  %10.0f rows/s" % (rows, name, dt * 1e6, rows / dt))
