@@ -342,6 +342,28 @@ def test_wide_tile_path(V, dtype):
     check_step_parity(V, archs, [True, False], [5.0, 1.0], 0.5, "softplus", 4096, dtype, steps=1)
 
 
+@pytest.mark.parametrize("env", [{"AVAE_TN_G": "2"}, {"AVAE_TN_G": "8"}, {"AVAE_NO_TN_BALANCE": "1"}, {"AVAE_NO_BIAS_MFMA": "1"},
+                                 {"AVAE_NO_256": "1"}])
+def test_planner_switches_big_launches(V, monkeypatch, env):
+    """The planner's A/B switches (read by avae_create) select other routes through the same kernels -- other XCD groupings of
+    the weight-gradient entries (8 leaves holes in the entry table), plan-order entries, bias rows as tile rows, 128x128
+    tiles -- and every route must give the same parity."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    archs = [make_arch("a", 784, 0, 0, 16, n_hidden=[1024, 768]), make_arch("b", 147, 0, 0, 16, n_hidden=[1024, 768])]
+    check_step_parity(V, archs, [True, False], [5.0, 1.0], 0.5, "softplus", 4096, "bf16", steps=1)
+
+
+@pytest.mark.parametrize("env", [{"AVAE_NO_THIN": "1"}, {"AVAE_NO_ADJ": "1"}, {"AVAE_NO_THIN": "1", "AVAE_NO_ADJ": "1"}])
+def test_planner_switches_conv_routes(V, monkeypatch, env):
+    """Conv stages through the patch-matrix route instead of the direct / adjoint-frame ones: same parity."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    img = dict(make_arch("image", 784, 8, 24, 6), hidden_conv=True, n_hidden_gener_1=24, n_hidden_gener_2=8)
+    jnt = make_arch("joint", 147, 40, 32, 6)
+    check_step_parity(V, [img, jnt], [True, False], [5.0, 1.0], 0.5, "relu", 12, "fp32", steps=1)
+
+
 def test_graph_replay_equals_eager(V):
     archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
     rng = np.random.default_rng(3)
