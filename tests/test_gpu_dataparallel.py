@@ -16,6 +16,9 @@ from conftest import make_arch, synth_batch
 pytestmark = pytest.mark.gpu
 
 ARCHS = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
+# the conv/deconv image branch next to the MLP joint branch: direct, adjoint-frame and patch-matrix stages, split reductions
+ARCHS_CONV = [dict(make_arch("image", 784, 8, 24, 20), hidden_conv=True, n_hidden_gener_1=24, n_hidden_gener_2=8),
+              make_arch("joint", 147, 40, 32, 20)]
 KW = dict(binary=[True, False], transfer_fct="relu", weights=[50.0, 1.0], assoc_lambda=8.0, seed=3)
 B_LOC, WORLD, STEPS = 32, 2, 3
 
@@ -27,7 +30,7 @@ def _data():
     return X, eps
 
 
-def _worker(rank, port, out_dir, dtype):
+def _worker(rank, port, out_dir, dtype, conv=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
@@ -35,6 +38,7 @@ def _worker(rank, port, out_dir, dtype):
         g.build()
         from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
         X, eps = _data()
+        ARCHS = ARCHS_CONV if conv else globals()["ARCHS"]
         m = AssocVariationalAutoEncoder(ARCHS, batch_size=B_LOC, compute_dtype=dtype, device=0, data_parallel=True, **KW)
         assert m._cfg.batch_global == B_LOC * WORLD and m._cfg.row_offset == rank * B_LOC
         lo, hi = rank * B_LOC, (rank + 1) * B_LOC
@@ -74,6 +78,26 @@ def test_two_hip_replicas_match_single_replica_global_batch(tmp_path, dtype):
     assert abs(float(r[0]["ev"]) - ref_ev) <= tol * abs(ref_ev)
     # fp32: weights track the global-batch run up to Adam's amplification of rounding-level gradient differences
     assert np.abs(r[0]["params"] - full.get_params()).max() <= (2e-4 if dtype == "fp32" else 7.5e-3)
+
+
+def test_two_hip_replicas_with_conv_modality(tmp_path):
+    """The same check with the conv/deconv image branch (its helper launches -- direct stage, adjoint-frame gradients, row / column
+    sums, split-K reductions -- all finish before the all-reduce reads the gradient buffer)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(port, str(tmp_path), "fp32", True), nprocs=WORLD, join=True)
+    import __graft_entry__ as g
+    g.build()
+    from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+    X, eps = _data()
+    full = AssocVariationalAutoEncoder(ARCHS_CONV, batch_size=B_LOC * WORLD, compute_dtype="fp32", device=0, **KW)
+    ref_costs = [full.partial_fit(X, eps[s]) for s in range(STEPS)]
+    r = [np.load(os.path.join(str(tmp_path), "r%d.npz" % k)) for k in range(WORLD)]
+    assert np.array_equal(r[0]["params"], r[1]["params"])
+    assert np.allclose(r[0]["costs"], ref_costs, rtol=1e-5)
+    assert np.abs(r[0]["params"] - full.get_params()).max() <= 5e-4
 
 
 def test_rccl_backend_collective_on_the_gradient_view():
