@@ -100,6 +100,51 @@ def test_two_hip_replicas_with_conv_modality(tmp_path):
     assert np.abs(r[0]["params"] - full.get_params()).max() <= 5e-4
 
 
+def _train_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        import __graft_entry__ as g
+        g.build()
+        from vae_assoc_amd import dataset, vae_assoc as V
+        rng = np.random.default_rng(23)
+        data = np.concatenate(synth_batch(rng, 400, [784, 147], [True, False]), axis=1)
+        np.random.seed(5)
+        ds = dataset.to_device(dataset.construct_datasets(data)) if rank == 0 else dataset.construct_datasets(data)   # device- and host-resident feeders
+        np.random.seed(1000 + rank)
+        m, hist = V.train(ds, ARCHS, binary=KW["binary"], weights=KW["weights"], assoc_lambda=KW["assoc_lambda"], batch_size=B_LOC,
+                          training_epochs=3, display_step=10, early_stop=2, compute_dtype="fp32", seed=3, device=0, data_parallel=True)
+        np.savez(os.path.join(out_dir, "t%d.npz" % rank), hist=np.array(hist), params=m.get_params())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_under_data_parallel_equals_global_batch_run(tmp_path):
+    """train(..., data_parallel=True) on two replicas (per-rank batch 32) == train(batch_size=64) in one process: the ranks walk
+    one shuffled data set in global batches and each takes its rows; eps comes from the in-kernel generator keyed by GLOBAL row."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_train_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    import __graft_entry__ as g
+    g.build()
+    from vae_assoc_amd import dataset, vae_assoc as V
+    rng = np.random.default_rng(23)
+    data = np.concatenate(synth_batch(rng, 400, [784, 147], [True, False]), axis=1)
+    np.random.seed(5)
+    ds = dataset.construct_datasets(data)
+    np.random.seed(1000)
+    np.random.seed(int(np.random.randint(0, 2 ** 31 - 1)))               # what train_loop broadcasts from rank 0
+    full, ref_hist = V.train(ds, ARCHS, binary=KW["binary"], weights=KW["weights"], assoc_lambda=KW["assoc_lambda"],
+                             batch_size=B_LOC * WORLD, training_epochs=3, display_step=10, early_stop=2, compute_dtype="fp32", seed=3, device=0)
+    r = [np.load(os.path.join(str(tmp_path), "t%d.npz" % k)) for k in range(WORLD)]
+    assert np.array_equal(r[0]["params"], r[1]["params"]) and np.array_equal(r[0]["hist"], r[1]["hist"])
+    assert len(ref_hist) == len(r[0]["hist"]) == 3 * (320 // (B_LOC * WORLD))
+    assert np.allclose(r[0]["hist"], ref_hist, rtol=2e-5)
+    assert np.abs(r[0]["params"] - full.get_params()).max() <= 5e-4
+
+
 def test_rccl_backend_collective_on_the_gradient_view():
     """The collective the data-parallel path issues, on the RCCL backend (one rank is all a one-GPU box offers):
     backward graph -> dist.all_reduce of the float32 view into the library's workspace -> Adam, over a run of steps,

@@ -381,11 +381,13 @@ def test_graph_replay_equals_eager(V):
 
 @pytest.mark.parametrize("given_eps", [False, True])
 def test_train_steps_equals_single_steps(V, given_eps):
-    """avae_train_steps (16 or 4 steps per graph replay, all their batches staged by one launch, re-pointed while earlier
-    replays are still in flight) is exactly n successive avae_train_step calls: bitwise equal costs and weights."""
+    """avae_train_steps (16 or 4 steps per graph replay, all their batches staged by one launch, each executable's staging node
+    re-pointed with hipGraphExecKernelNodeSetParams while its previous replay is still queued) is exactly n successive
+    avae_train_step calls: bitwise equal costs and weights."""
     archs = [make_arch("image", 784, 64, 48, 8), make_arch("joint", 147, 40, 32, 8)]
     rng = np.random.default_rng(9)
-    n, B = 21, 32                                          # one replay of 16 steps, one of 4, one single step
+    n, B = 41, 32                                          # 16 + 16 + 4 + 4 + 1: every multi-step executable is re-pointed and
+                                                           # replayed twice back to back, with no synchronise in between
     data = np.concatenate(synth_batch(rng, n * B, [784, 147], [True, False]), axis=1)
     dev = torch.as_tensor(data).cuda()
     X = [dev[:, :784], dev[:, 784:]]                       # column slices of one matrix: row stride 931
@@ -410,11 +412,11 @@ def test_train_steps_equals_single_steps(V, given_eps):
 
 def test_train_steps_with_conv_modality(V):
     """The staging-set relocation of the multi-step replays also covers the conv branch (its first im2col reads the
-    staged image): a run of 6 batches (one replay of 4 + 2 single steps) equals 6 single steps, bitwise."""
+    staged image): a run of 41 batches (replays of 16, 16, 4, 4 steps + a single step) equals 41 single steps, bitwise."""
     img = dict(make_arch("image", 784, 8, 16, 6), hidden_conv=True, n_hidden_gener_1=16, n_hidden_gener_2=8)
     jnt = make_arch("joint", 147, 24, 16, 6)
     rng = np.random.default_rng(13)
-    n, B = 6, 8
+    n, B = 41, 8                                            # 16 + 16 + 4 + 4 + 1, as above
     data = np.concatenate(synth_batch(rng, n * B, [784, 147], [True, False]), axis=1)
     dev = torch.as_tensor(data).cuda()
     X = [dev[:, :784], dev[:, 784:]]
@@ -557,6 +559,52 @@ def test_internal_eps_is_philox_normal_and_shard_consistent(V):
     half.set_params(m.get_params())
     half.partial_fit([x[256:] for x in X], return_cost=False)
     assert np.array_equal(fetch(half, "eps", (256, 20)), e0[256:])
+
+
+def test_internal_eps_is_fresh_per_call_modality_and_chunk(V):
+    """with eps=None every evaluate_cost / reconstruct call draws its own noise, as each sess.run of the reference
+    does (vae_assoc.py:90, 388-391, 421-425): different across calls with no training step in between, across modalities, and
+    across the batch_size-row chunks of a long input; and it is N(0,1).  The decoder of an IDENTITY-like probe is not available,
+    so the noise is read back through the library's eps buffer (last chunk) and through its effect on the outputs."""
+    archs = [make_arch("image", 784, 32, 24, 20), make_arch("joint", 147, 24, 16, 20)]
+    B = 256
+    rng = np.random.default_rng(2)
+    m = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="relu", batch_size=B, compute_dtype="fp32", seed=5)
+    X = synth_batch(rng, B, [784, 147], [True, False])
+    # evaluate_cost twice with no step in between: two draws
+    m.evaluate_cost(X)
+    e0 = fetch(m, "eps", (B, 20)).copy()
+    c1 = m.evaluate_cost(X)
+    e1 = fetch(m, "eps", (B, 20)).copy()
+    assert not np.array_equal(e0, e1) and abs(np.corrcoef(e0.ravel(), e1.ravel())[0, 1]) < 0.05
+    for e in (e0, e1):
+        assert abs(e.mean()) < 0.05 and abs(e.std() - 1) < 0.05
+    assert m.evaluate_cost(X) != c1
+    # reconstruct: a draw per modality (the eps buffer holds the LAST modality's after the call) and per call
+    same = [X[1], X[1]]                                    # feed modality 1's rows to a model with two identical joint branches
+    twin = V.AssocVariationalAutoEncoder([archs[1], dict(archs[1], scope="joint2")], binary=[False, False], transfer_fct="relu",
+                                         batch_size=B, compute_dtype="fp32", seed=5)
+    p = twin.get_params()
+    half = p.size // 2
+    p[half:] = p[:half]                                    # same weights in both branches: outputs differ only through eps
+    twin.set_params(p)
+    r1 = twin.reconstruct(same)
+    assert np.abs(r1[0] - r1[1]).max() > 1e-3, "both modalities reconstructed with the same noise"
+    r2 = twin.reconstruct(same)
+    assert np.abs(r1[0] - r2[0]).max() > 1e-3, "two reconstruct calls drew the same noise"
+    # rows beyond batch_size: chunk 2 must not repeat chunk 1's noise (same input rows in both chunks -> outputs would be equal)
+    long = [np.concatenate([X[1], X[1]]), np.concatenate([X[1], X[1]])]
+    r3 = twin.reconstruct(long)
+    assert np.abs(r3[0][:B] - r3[0][B:]).max() > 1e-3, "rows r and r + batch_size got identical noise"
+    # explicit eps is still honoured exactly
+    eg = rng.standard_normal((2 * B, 20)).astype(np.float32)
+    r4, r5 = twin.reconstruct(long, eps=[eg, eg]), twin.reconstruct(long, eps=[eg, eg])
+    assert np.array_equal(r4[0], r5[0]) and np.array_equal(r4[0], r4[1])
+    # the training stream is untouched by the draws above (documented counter layout, checked in the test before this one)
+    m.partial_fit(X)
+    want = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="relu", batch_size=B, compute_dtype="fp32", seed=5)
+    want.partial_fit(X)
+    assert np.array_equal(fetch(m, "eps", (B, 20)), fetch(want, "eps", (B, 20)))
 
 
 # ----------------------------------------------------------------------------- data-parallel property on one GPU

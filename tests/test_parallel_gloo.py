@@ -84,6 +84,92 @@ def test_two_rank_step_equals_single_process_global_batch(tmp_path):
     assert r[0]["tot"] == 3.0
 
 
+# ----------------------------------------------------------------------------- train() under data parallelism
+N_ROWS, EPOCHS = 64, 3          # -> 51 training rows after the 80/10/10 split: 4 global batches of 12 per epoch, reshuffles on wrap
+
+
+def _train_data():
+    rng = np.random.default_rng(77)
+    data = np.concatenate(synth_batch(rng, N_ROWS, [a["n_input"] for a in ARCHS], BIN), axis=1)
+    eps = rng.standard_normal((64, B_GLOBAL, 5))
+    p0 = O.flatten_params(ARCHS, O.init_params(ARCHS, np.random.default_rng(1)))
+    return data, eps, p0
+
+
+class TrainReplica(OracleReplica):
+    """partial_fit / evaluate_cost as vae_assoc.AssocVariationalAutoEncoder offers them under data_parallel=True: local rows
+    in, global-batch cost out; eps of step s = rows [lo, hi) of the global eps of that step."""
+
+    def __init__(self, sync, eps_all, p0):
+        bl = B_GLOBAL // sync.world_size
+        OracleReplica.__init__(self, bl, B_GLOBAL, p0)
+        self._sync, self.eps_all, self.step = sync, eps_all, 0
+        self.lo, self.hi = sync.local_rows(bl)
+
+    def partial_fit(self, X):
+        c = dp_train_step(self, self._sync, X, self.eps_all[self.step][self.lo:self.hi])
+        self.step += 1
+        return c
+
+    def evaluate_cost(self, X):
+        c, _, _ = self.model.cost_and_grads(X, self.eps_all[-1][self.lo:self.hi], batch_global=self.batch_global)
+        return self._sync.sum_scalar(c, "cpu")
+
+
+def _train_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from vae_assoc_amd import dataset
+        from vae_assoc_amd.vae_assoc import train_loop
+        data, eps, p0 = _train_data()
+        np.random.seed(5)                                   # same split on every rank
+        ds = dataset.construct_datasets(data.copy())
+        np.random.seed(1000 + rank)                         # ranks arrive with DIFFERENT RNG states: train_loop must align them
+        sync = GradSync()
+        rep = TrainReplica(sync, eps, p0)
+        _m, hist = train_loop(rep, ds, ARCHS, B_GLOBAL // WORLD, training_epochs=EPOCHS, display_step=100, early_stop=2, sync=sync)
+        seed_after = int(np.random.randint(0, 2 ** 31 - 1))
+        np.savez(os.path.join(out_dir, "t%d.npz" % rank), hist=np.array(hist), params=rep.model.get_params(), steps=rep.step,
+                 seed_after=seed_after)
+        # ranks that hold different data are refused
+        bad = dataset.construct_datasets(data.copy() + (0.5 if rank else 0.0), shuffle=False)
+        try:
+            train_loop(TrainReplica(sync, eps, p0), bad, ARCHS, B_GLOBAL // WORLD, training_epochs=1, sync=sync)
+            raised = False
+        except ValueError:
+            raised = True
+        assert raised
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_loop_shards_global_batches(tmp_path):
+    """train() under data parallelism must walk ONE shuffled data set in global batches of world*B rows, rank r
+    taking rows [r*B, (r+1)*B) of each -- the run then equals the single-process run with batch_size = world*B: same number of
+    steps, same avg_cost_hist (global-batch cost, weight B_global/n_samples), same weights."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_train_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "t%d.npz" % k)) for k in range(WORLD)]
+    assert np.array_equal(r[0]["params"], r[1]["params"]) and np.array_equal(r[0]["hist"], r[1]["hist"])
+    assert int(r[0]["seed_after"]) == int(r[1]["seed_after"])            # the ranks' shuffles stayed aligned
+    # single process, global batch: the oracle's own restatement of the reference loop (vae_assoc.py:498-583), seeded like rank 0
+    from vae_assoc_amd import dataset
+    data, eps, p0 = _train_data()
+    np.random.seed(5)
+    ds = dataset.construct_datasets(data.copy())
+    np.random.seed(1000)
+    np.random.seed(int(np.random.randint(0, 2 ** 31 - 1)))               # what train_loop broadcasts from rank 0
+    ref, ref_hist = O.train(ds, ARCHS, binary=BIN, weights=W, assoc_lambda=LAM, learning_rate=LR, batch_size=B_GLOBAL,
+                            training_epochs=EPOCHS, early_stop=2, params_flat=p0, eps_fn=lambda st: eps[st])
+    assert int(r[0]["steps"]) == len(ref_hist) == EPOCHS * (ds.train._data.shape[0] // B_GLOBAL)
+    assert np.allclose(r[0]["hist"], ref_hist, rtol=1e-11)
+    assert np.abs(r[0]["params"] - ref.get_params()).max() < 1e-11
+
+
 def test_gradsync_requires_process_group():
     import pytest
     if dist.is_initialized():

@@ -14,7 +14,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
 for tag, defs in (("full", []), ("no_mfma", ["-DAVAE_ABL_NO_MFMA"]), ("no_dma", ["-DAVAE_ABL_NO_DMA"])):
     out = os.path.join(ROOT, "gpurun_out", "abl_" + tag)
     shutil.rmtree(out, ignore_errors=True)
-    shutil.copytree(ROOT, out, ignore=shutil.ignore_patterns("gpurun_out", ".git", "*.so", "__pycache__", "profiles"))
+    shutil.copytree(ROOT, out, ignore=shutil.ignore_patterns("gpurun_out", ".git", "*.so", "__pycache__", "profiles", "tests"))
     src = [os.path.join(out, "vae_assoc_amd", "csrc", f) for f in ("avae_kernels.hip", "avae_host.hip")]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + defs + src
                    + ["-o", os.path.join(out, "vae_assoc_amd", "libavae.so")], check=True)

@@ -31,6 +31,27 @@ struct Err : std::runtime_error { using std::runtime_error::runtime_error; };
                       std::to_string(__LINE__) + ")");                                           \
     } while (0)
 
+// The calling thread's current HIP device is put back on exit: a process may hold a model on device k while its own (torch)
+// current device is j, and every ABI call switching the thread to k would silently move the caller's later allocations.
+struct DeviceGuard {
+    int prev = -1, want = -1;
+    explicit DeviceGuard(int dev) : want(dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) HIP_OK(hipSetDevice(want));
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// A launch rejected by the runtime (grid / LDS size, bad kernel arguments) must surface as this call's error, not later as a
+// wrong number.  Also legal while a stream is being captured.
+#define LAUNCH_OK(what)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = hipGetLastError();                                                       \
+        if (e_ != hipSuccess) throw Err(std::string("launch of ") + (what) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
 constexpr int kMultiSteps = 16;         // most whole steps per replay of a multi-step graph (avae_train_steps) = staging sets
 constexpr int kMultiSizes[2] = {16, 4};  // captured replay lengths: a run of n batches goes 16,16,...,4,4,...,1,1
 
@@ -162,6 +183,7 @@ struct avae_handle {
     hipGraphNode_t g_full_prep = nullptr, g_multi_prep[2] = {nullptr, nullptr};
     std::vector<hipGraphExec_t> g_bwd_set;  // data-parallel runs: forward + backward + wgrad on staging set j (captured on first use)
 
+    unsigned draw_id = 0;                   // eval / reconstruct calls that drew their own eps (keys the generator: a fresh draw per call)
     bool timing = false;
     bool debug_sync = false;
     std::vector<std::string> tnames;
@@ -1259,6 +1281,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         else if (L.type == 8) launch_rowsum(h->cfg.compute_dtype, L.rs, L.blocks, s);
         else if (L.tn) launch_grouped_tn(h->cfg.compute_dtype, L.cfg, L.targs, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
+        LAUNCH_OK(L.name);
         if (h->debug_sync) {      // AVAE_DEBUG_SYNC=1: name the launch a fault belongs to
             std::fprintf(stderr, "[avae] launch %s type=%d cfg=%d items=%d blocks=%d\n", L.name.c_str(), L.type, L.cfg, L.count, L.blocks);
             for (int i = 0; i < L.args.n_items && L.type == 0; ++i)
@@ -1290,6 +1313,7 @@ void run_adam(avae_handle* h, int mode, hipStream_t s) {
     a.cost_src = h->grad() + h->P_int;
     Timed t(h, s, mode == 0 ? "adam" : "shadow_refresh");
     launch_adam(h->cfg.compute_dtype, a, h->adam_blocks, s);
+    LAUNCH_OK(mode == 0 ? "adam" : "shadow_refresh");
 }
 
 // stages the caller's batch (and eps) into the internal compute-dtype buffers
@@ -1321,10 +1345,11 @@ void run_prep_batch(avae_handle* h, const float* const* x, const int32_t* x_ld, 
     const PrepArgs a = make_prep_batch(h, x, x_ld, eps, rows, salt);
     Timed t(h, s, "prep");
     launch_prep(h->cfg.compute_dtype, a, s);
+    LAUNCH_OK("prep");
 }
 
 void run_prep_single(avae_handle* h, const float* src, int src_ld, int rows, int cols, const Act& dst, float* dst32, int ld32,
-                     bool do_eps, const float* eps, unsigned long long salt, hipStream_t s) {
+                     bool do_eps, const float* eps, unsigned long long salt, hipStream_t s, int row0 = 0) {
     PrepArgs a;
     std::memset(&a, 0, sizeof(a));
     if (src) {
@@ -1339,8 +1364,9 @@ void run_prep_single(avae_handle* h, const float* src, int src_ld, int rows, int
         a.eps_src = eps; a.eps_dst = h->at<float>(h->off_eps); a.eps_rows = rows; a.nz = h->nz; a.eps_ld = h->ld_eps;
         a.eps_blocks = (rows * ((h->nz + 3) / 4) + kThreads - 1) / kThreads;
     }
-    a.row_offset = h->cfg.row_offset; a.seed = h->cfg.seed; a.st = h->state(); a.stream_salt = salt;
+    a.row_offset = h->cfg.row_offset + row0; a.seed = h->cfg.seed; a.st = h->state(); a.stream_salt = salt;
     launch_prep(h->cfg.compute_dtype, a, s);
+    LAUNCH_OK("prep");
 }
 
 // The same launch reading staging set j instead of set 0: every pointer into set 0 moves by j * stage_bytes.
@@ -1415,6 +1441,7 @@ void fill_ones(avae_handle* h, const Act& a, hipStream_t s) {
     if (!a.ones) return;
     const unsigned bits = h->es == 2 ? 0x3F80u : 0x3F800000u;
     launch_fill(h->at<void>(a.rm), h->es, bits, a.width, a.ld, h->B, s);             // column `width`, rows < B
+    LAUNCH_OK("fill");
 }
 
 void init_device(avae_handle* h) {
@@ -1457,6 +1484,7 @@ void init_device(avae_handle* h) {
         for (int gi = 0; gi < 2; ++gi) h->g_multi[gi] = capture_with_prep(h, [&](hipStream_t cs) {
             const PrepArgs a = make_prep_batch(h, x0.data(), nullptr, nullptr, h->B, 0x7261696eull, kMultiSizes[gi]);
             launch_prep(h->cfg.compute_dtype, a, cs);
+            LAUNCH_OK("prep");
             for (int j = 0; j < kMultiSizes[gi]; ++j) {
                 for (const std::vector<Launch>* ls : {&h->fwd, &h->bwd, &h->wgrad}) {
                     std::vector<Launch> moved;
@@ -1497,7 +1525,7 @@ template <typename F> int guarded(avae_handle* h, F&& f) {
     if (!h) return 1;
     std::lock_guard<std::mutex> lk(h->mu);
     try {
-        HIP_OK(hipSetDevice(h->cfg.device));
+        DeviceGuard dg(h->cfg.device);
         f();
         return 0;
     } catch (const std::exception& e) {
@@ -1547,7 +1575,7 @@ int avae_create(const avae_config* cfg, avae_handle** out) {
         HIP_OK(hipGetDeviceCount(&ndev));
         if (ndev < 1) throw Err("no HIP device: libavae has no CPU fallback");
         if (h->cfg.device < 0 || h->cfg.device >= ndev) throw Err("device ordinal out of range");
-        HIP_OK(hipSetDevice(h->cfg.device));
+        DeviceGuard dg(h->cfg.device);
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, h->cfg.device));
         if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
@@ -1574,6 +1602,8 @@ int avae_create(const avae_config* cfg, avae_handle** out) {
 
 void avae_destroy(avae_handle* h) {
     if (!h) return;
+    int prev_dev = -1;
+    if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     for (hipGraphExec_t g : {h->g_full, h->g_multi[0], h->g_multi[1], h->g_bwd, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
@@ -1582,6 +1612,7 @@ void avae_destroy(avae_handle* h) {
     for (TimingRec& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->own_ws && h->ws) (void)hipFree(h->ws);
+    if (prev_dev >= 0 && prev_dev != h->cfg.device) (void)hipSetDevice(prev_dev);
     delete h;
 }
 
@@ -1656,6 +1687,7 @@ int avae_stage_batches(avae_handle* h, int32_t n_steps, const float* const* x_de
         const PrepArgs a = make_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, n_steps);
         Timed t(h, s, "prep");
         launch_prep(h->cfg.compute_dtype, a, s);
+        LAUNCH_OK("prep");
     });
 }
 
@@ -1694,6 +1726,7 @@ void train_one(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, c
     if (h->timing) {      // floor of the measurement: a one-store kernel (partial slot 0 is rewritten every step anyway)
         Timed t(h, s, "_null_kernel");
         launch_fill(h->at<void>(h->off_partial), 4, 0u, 0, 1, 1, s);
+        LAUNCH_OK("_null_kernel");
     }
 }
 
@@ -1756,7 +1789,9 @@ int avae_cost_history(avae_handle* h, int32_t n, float* host_dst, int64_t* last_
 int avae_eval_cost(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, float* cost_host, void* stream) {
     return guarded(h, [&] {
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x6576616cull /*eval*/, s);
+        // a fresh eps per call, as each sess.run of the reference draws one (vae_assoc.py:90,388-391): the draw counter keys it
+        const unsigned long long draw = eps_dev ? 0ull : (unsigned long long)((++h->draw_id) & 0x3FFFFFu) << 34;
+        run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x6576616cull /*eval*/ | draw, s);
         if (h->g_eval && !h->timing) HIP_OK(hipGraphLaunch(h->g_eval, s));
         else { run_launches(h, h->fwd, s); run_launches(h, std::vector<Launch>{h->cost_only}, s); }
         fetch_cost(h, cost_host, false, s);
@@ -1809,12 +1844,13 @@ int avae_reconstruct(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         const Mod& md = h->mods[m];
         const int ld = x_ld > 0 ? x_ld : md.n_in;
+        // a fresh eps per call and per modality, as each sess.run of the reference draws one (vae_assoc.py:423-424): the salt's
+        // high word carries (draw counter, modality), the generator's row index is the row of the whole input (r0 + row)
+        const unsigned long long draw = eps_dev ? 0ull : ((unsigned long long)((++h->draw_id) & 0x3FFFFFu) << 34) | ((unsigned long long)m << 32);
         for (int r0 = 0; r0 < rows; r0 += h->B) {
             const int n = std::min(h->B, rows - r0);
-            // a fresh eps per call and per modality, as each sess.run of the reference draws one (vae_assoc.py:423-424)
             run_prep_single(h, x_dev + (size_t)r0 * ld, ld, n, md.n_in, md.X0, nullptr, 0, true,
-                            eps_dev ? eps_dev + (size_t)r0 * h->nz : nullptr,
-                            0x7265636full + ((unsigned long long)m << 40) + ((unsigned long long)(r0 / h->B) << 44), s);
+                            eps_dev ? eps_dev + (size_t)r0 * h->nz : nullptr, 0x7265636full | draw, s, r0);
             run_inference(h, m, true, n, s);
             run_inference(h, m, false, n, s);
             copy_rows(xhat_dev + (size_t)r0 * md.n_in, (size_t)md.n_in * 4, h->at<float>(md.out32), (size_t)md.ld32 * 4, (size_t)md.n_in * 4, n, s);

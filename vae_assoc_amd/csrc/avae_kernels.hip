@@ -1,21 +1,19 @@
 // gfx950 (MI355X, CDNA4) kernels of the associative-VAE training path.
 //
-// One grouped kernel does every matrix product of the step.  All products are brought to the
-// same "NT" form  C[M,N] = sum_k A[m][k] * B[n][k]  (both operands K-contiguous in HBM, K padded
-// with zeros to 128-byte units) by keeping, next to every activation / gradient / weight, its
-// transposed copy, written by the producing epilogue:
-//     forward   Y  = X_aug . W_aug        A = X_aug  [B][in+1]      B = W_aug^T [out][in+1]
-//     dgrad     dX = dA . W^T             A = dA     [B][out]       B = W_aug   [in+1][out]
-//     wgrad     dW_aug = X_aug^T . dA     A = X_aug^T [in+1][B]     B = dA^T    [out][B]
-// The bias is the last row of W_aug and every activation carries a constant-1 column, so the
-// bias add and the bias gradient fall out of the same MFMA products.
+// One grouped kernel does every matrix product of the step, on the operands AS THEY ARE STORED (row-major, K padded with
+// zeros to 128-byte units); no transposed copy of any activation or gradient exists:
+//     forward   Y  = X_aug . W_aug        "NT"  A = X_aug [B][in+1]     B = W_aug^T shadow [out][in+1]   (both K-contiguous)
+//     dgrad     dX = dA . W^T             "NT"  A = dA    [B][out]      B = W_aug shadow   [in+1][out]
+//     wgrad     dW_aug = X_aug^T . dA     "TN"  A = X_aug [B][in+1]     B = dA [B][out]    (K = batch: K-major LDS images,
+//                                               fragments by ds_read_b64_tr_b16)
+// The bias is the last row of W_aug and every activation carries a constant-1 column, so the bias add and the bias gradient
+// fall out of the same MFMA products.
 //
-// Per workgroup: a BM x BN output tile -- 64x64 or 128x128 with 4 wave64s (2x2), or 256x128 with 8 wave64s (4x2) --
-// v_mfma_f32_16x16x32_bf16 (bf16 operands) or v_mfma_f32_16x16x4_f32 (exact fp32), fp32 accumulation in
-// registers, a 4- / 2- / 3-stage LDS-DMA ring (global_load_lds_dwordx4, XOR-swizzled 128-byte rows:
-// conflict-free ds_read_b128, up to RING-1 K tiles in flight), and an LDS-staged epilogue that fuses the
-// activation / reparameterisation / loss / gradient maths and writes both the row-major and the transposed
-// result with coalesced vector stores.  What bounds the loop and why the tiles are what they are: DESIGN.md, section 4.
+// Per workgroup: a BM x BN output tile -- 32x32 ... 128x128 with 4 wave64s (2x2), or 256x128 with 8 wave64s (4x2) --
+// v_mfma_f32_16x16x32_bf16 (bf16 operands) or v_mfma_f32_16x16x4_f32 (exact fp32), fp32 accumulation in registers, a 2- to
+// 4-stage LDS-DMA ring (global_load_lds_dwordx4, XOR-swizzled 128-byte rows: conflict-free ds_read_b128, up to RING-1 K tiles
+// in flight), and an epilogue that fuses the activation / reparameterisation / loss / gradient maths and writes every result
+// ONCE, row-major, with 16-byte stores.  What bounds the loop and why the tiles are what they are: DESIGN.md, section 4.
 //
 // Reference maths: /root/reference/vae_assoc.py:163-222 (encoder), :243-304 (decoder),
 // :306-371 (losses), :373-374 (Adam); restated for CPU in oracle/vae_assoc_oracle.py.
@@ -1042,7 +1040,7 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
     const int bid = (int)blockIdx.x - bstep * a.blocks_per_step;
     const size_t set_off = (size_t)bstep * (size_t)a.set_stride;                      // bytes to that step's staging set
     if (bid >= a.total_tiles) {
-        // eps: one quad of dims per thread; counter = (global row, quad, step lo, step hi ^ salt)
+        // eps: one quad of dims per thread
         if (!a.eps_dst) return;
         const int nq = (a.nz + 3) / 4;
         const int q = (bid - a.total_tiles) * kThreads + tid;
@@ -1056,7 +1054,9 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
         } else {
             const unsigned long long step = (unsigned long long)a.st->step + (unsigned long long)bstep;
             unsigned r[4];
-            philox4x32_10((unsigned)(a.row_offset + row), (unsigned)d4, (unsigned)step,
+            // counter = (global row, dim quad ^ salt.hi << 8, step lo, step hi ^ salt.lo): the salt's low word names the stream
+            // (train / eval / reconstruct), its high word the draw (per-handle draw counter, modality) -- 0 for training
+            philox4x32_10((unsigned)(a.row_offset + row), (unsigned)d4 ^ ((unsigned)(a.stream_salt >> 32) << 8), (unsigned)step,
                           (unsigned)(step >> 32) ^ (unsigned)a.stream_salt,
                           (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
             // Box-Muller on (0,1) uniforms built from the top 24 bits

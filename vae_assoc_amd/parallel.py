@@ -39,9 +39,18 @@ class GradSync(object):
         return flat
 
     def sum_scalar(self, value, device):
-        t = torch.tensor([float(value)], dtype=torch.float32, device=device)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device)
         self.all_reduce_(t)
         return float(t.item())
+
+    def broadcast_int(self, value, src=0):
+        """rank `src`'s integer on every rank (train(): one NumPy seed for the shuffles of all ranks)"""
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        if self.world_size > 1:
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=src, group=self.group)
+        return int(t.item())
 
     def local_rows(self, batch_local):
         """Row range of this rank inside the global batch."""

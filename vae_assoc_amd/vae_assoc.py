@@ -473,34 +473,76 @@ def train(data_sets, network_architectures, binary=True, weights=1.0, assoc_lamb
     Runs of consecutive ``next_batch`` slices (everything between two reshuffles) are handed over as one
     matrix and trained in one submission (``partial_fit_steps``); the matrix is split into modalities on
     the device by pointer offset + row stride (no per-modality copies); per-step costs are read back once
-    per epoch from the device-side history, so the hot loop never synchronises."""
+    per epoch from the device-side history, so the hot loop never synchronises.
+
+    ``data_parallel=True`` (one process per GPU): ``batch_size`` is the per-rank batch; every rank walks the SAME
+    data set in the SAME order in global batches of ``world * batch_size`` rows and trains on its own rows of each
+    (see ``train_loop``), so the run equals the single-process run with ``batch_size * world``."""
     vae_assoc = AssocVariationalAutoEncoder(network_architectures, binary, transfer_fct="relu", weights=weights,
                                             assoc_lambda=assoc_lambda, learning_rate=learning_rate,
                                             batch_size=batch_size, **model_kwargs)
+    return train_loop(vae_assoc, data_sets, network_architectures, batch_size, training_epochs, display_step, early_stop)
+
+
+def train_loop(vae_assoc, data_sets, network_architectures, batch_size, training_epochs=10, display_step=5,
+               early_stop=False, sync=None, device=None):
+    """The loop of ``train`` on an already built model (any object with ``partial_fit`` / ``evaluate_cost``, and optionally
+    ``partial_fit_steps`` / ``cost_history``; the CPU tests drive it with an oracle-backed replica).
+
+    Data parallelism (``sync`` = the model's ``GradSync``, world > 1): the reference's loop (vae_assoc.py:516-577) is kept, with
+    the global batch ``B_g = world * batch_size`` in the place of ``batch_size``: ``next_batch(B_g)`` on every rank -- rank 0's
+    NumPy seed is broadcast first, and a checksum of the training matrix is compared, so that all ranks shuffle alike --
+    rank r trains on rows [r*batch_size, (r+1)*batch_size) of it, ``total_batch = n_samples // B_g`` and the (already
+    all-reduced, global-batch) cost enters ``avg_cost`` with weight ``B_g / n_samples``."""
+    if sync is None:
+        sync = getattr(vae_assoc, "_sync", None)
+    world = sync.world_size if sync is not None else 1
+    rank = sync.rank if sync is not None else 0
     n_samples = data_sets.train._data.shape[0]
     sens_indices = np.concatenate([[0], np.cumsum([na["n_input"] for na in network_architectures])])
     n_mod = len(network_architectures)
     avg_cost_hist = []
     valid_cost = None
-    dev = vae_assoc.device
+    dev = device if device is not None else getattr(vae_assoc, "device", None)
     hist_cap = 4096
+    batch_global = batch_size * world
+    lo, hi = rank * batch_size, (rank + 1) * batch_size
+    if world > 1:
+        np.random.seed(sync.broadcast_int(int(np.random.randint(0, 2 ** 31 - 1))))
+        d = data_sets.train._data
+        probe = d[:: max(1, n_samples // 64)]
+        chk = float(probe.double().sum().item()) if torch.is_tensor(probe) else float(np.asarray(probe, dtype=np.float64).sum())
+        if abs(sync.sum_scalar(chk, "cpu" if dev is None else dev) - world * chk) > 1e-6 * max(1.0, abs(world * chk)):
+            raise ValueError("data_parallel train(): the ranks hold different training matrices (or different orders of one); "
+                             "build the data sets from the same array with the same NumPy seed on every rank")
 
     def seg(batch_xs):
         # host batches (reference DataSet) are uploaded once per step; a dataset.DeviceDataSet hands device rows
-        t = batch_xs if torch.is_tensor(batch_xs) else torch.as_tensor(np.ascontiguousarray(batch_xs, dtype=np.float32))
-        t = t.to(dev)
+        if dev is None:
+            t = np.asarray(batch_xs)
+        else:
+            t = batch_xs if torch.is_tensor(batch_xs) else torch.as_tensor(np.ascontiguousarray(batch_xs, dtype=np.float32))
+            t = t.to(dev)
         return [t[:, sens_indices[k]:sens_indices[k + 1]] for k in range(n_mod)]
 
+    def shard_run(batch_xs, n):
+        """rows of this rank inside each of the n consecutive global batches, as one matrix of n*batch_size rows"""
+        if world == 1:
+            return batch_xs
+        t = batch_xs.reshape(n, batch_global, batch_xs.shape[1])[:, lo:hi]
+        return t.reshape(n * batch_size, batch_xs.shape[1])
+
+    multi = hasattr(vae_assoc, "partial_fit_steps") and hasattr(vae_assoc, "cost_history")
     for epoch in range(training_epochs):
         avg_cost = 0.
-        total_batch = int(n_samples / batch_size)
+        total_batch = int(n_samples / batch_global)
         if early_stop:
             if epoch % early_stop == 0:
                 curr_valid_cost = 0
-                n_valid_batches = int(data_sets.validation._data.shape[0] / batch_size)
+                n_valid_batches = int(data_sets.validation._data.shape[0] / batch_global)
                 for i in range(n_valid_batches):
-                    batch_xs, _ = data_sets.validation.next_batch(batch_size)
-                    curr_valid_cost += vae_assoc.evaluate_cost(seg(batch_xs)) / n_valid_batches
+                    batch_xs, _ = data_sets.validation.next_batch(batch_global)
+                    curr_valid_cost += vae_assoc.evaluate_cost(seg(shard_run(batch_xs, 1))) / n_valid_batches
                 print("Validation cost=", "{:.9f}".format(curr_valid_cost))
                 if valid_cost is not None:
                     if curr_valid_cost > valid_cost:
@@ -511,17 +553,19 @@ def train(data_sets, network_architectures, binary=True, weights=1.0, assoc_lamb
         while done < total_batch:
             chunk = min(hist_cap, total_batch - done)
             got = 0
+            costs = []
             while got < chunk:
-                if hasattr(data_sets.train, "next_batches"):     # a run of consecutive slices = one submission
-                    batch_xs, _, n = data_sets.train.next_batches(batch_size, chunk - got)
-                    vae_assoc.partial_fit_steps(seg(batch_xs), n, return_cost=False)
+                if multi and hasattr(data_sets.train, "next_batches"):     # a run of consecutive slices = one submission
+                    batch_xs, _, n = data_sets.train.next_batches(batch_global, chunk - got)
+                    vae_assoc.partial_fit_steps(seg(shard_run(batch_xs, n)), n, return_cost=False)
                 else:                                             # a reference-style DataSet object
-                    batch_xs, _ = data_sets.train.next_batch(batch_size)
-                    vae_assoc.partial_fit(seg(batch_xs), return_cost=False)
+                    batch_xs, _ = data_sets.train.next_batch(batch_global)
+                    c = vae_assoc.partial_fit(seg(shard_run(batch_xs, 1)), **({"return_cost": False} if multi else {}))
+                    costs.append(c)
                     n = 1
                 got += n
-            for cost in vae_assoc.cost_history(chunk):
-                avg_cost += float(cost) / n_samples * batch_size
+            for cost in (vae_assoc.cost_history(chunk) if multi else costs):
+                avg_cost += float(cost) / n_samples * batch_global
                 avg_cost_hist.append(avg_cost)
             done += chunk
         if epoch % display_step == 0:
