@@ -48,6 +48,9 @@ struct WorkItem {
     int bias_row;            // K_WGRAD, > 0: the tiles cover rows [0, M) = the weight rows only and the bias gradient (row
                              // bias_row = M, the column sums of dA) comes from one extra MFMA per fragment with an all-ones A
                              // operand in the first tile row -- set by the host when M+1 rows would cost a whole tile row more
+    int bias_ep;             // forward kinds on the 8-wave tiles, set by the host when fan-in % K-unit == 0: K stops at the fan-in
+                             // (the bias row would cost a whole K tile more) and the epilogue adds bias[n] = aux1[n] instead
+    int kin;                 // forward kinds: fan-in of the layer (the bias is row kin of W_aug)
     int tile_off, tile_cnt;  // K_WGRAD launches only (TnItem)
     int slot_base;           // first cost-partial slot written by this item
     int n_slots;             // K_COST: number of partial slots to sum
@@ -76,13 +79,17 @@ struct WorkItem {
 // segment together with the first block index of every item: a workgroup finds and reads its item
 // without a chain of dependent loads from HBM, and no device-side table has to be kept in sync.
 constexpr int kMaxItemsPerLaunch = 12;
+constexpr int kMaxPf = 4;
 // Grid: x = tile slot inside an item (a multiple of 8, at least the largest item's tile count), y = item.
 // A workgroup knows its item from blockIdx.y alone, so its WorkItem is ONE scalar-load round trip into the
 // kernel-argument segment away; workgroups beyond their item's last tile exit at once.
 struct LaunchArgs {
     int n_items;
     int grid_x;
-    int pad[2];
+    int sched;               // diagnostics (AVAE_SCHED): 0 = the shipped in-loop order of the 8-wave tiles, 1 = round 1's order
+    int n_pf;                // 8-wave NT tiles: weight panels of the NEXT launch to pull into the Infinity Cache (0..kMaxPf)
+    const void* pf_ptr[4];   // ... their first bytes
+    int pf_lines[4];         // ... and sizes in 128-byte lines
     WorkItem items[kMaxItemsPerLaunch];
 };
 
@@ -106,7 +113,7 @@ struct TnLaunchArgs {
     int n_items;
     int grid_x;
     int xcd_group;           // G = 1, 2, 4 or 8 items share the 8 XCDs: each item's tiles run on 8/G of them (see k_grouped)
-    int pad;
+    int sched;               // as LaunchArgs::sched
     TnItem items[kMaxTnItems];
 };
 

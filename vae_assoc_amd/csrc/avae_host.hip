@@ -491,6 +491,7 @@ struct Builder {
         WorkItem w = gemm_item(K_FWD_HIDDEN, B, d.out, K_of(d.in + 1), p<void>(in.rm), in.ld, p<void>(d.Wt), d.ldt);
         w.act = h->cfg.activation;
         w.out0 = p<void>(out.rm); w.ld0 = out.ld;
+        w.kin = d.in; w.aux1 = p<unsigned char>(d.W) + (size_t)d.in * d.ld * h->es; w.ld1 = d.ld;   // bias row (see WorkItem::bias_ep)
         return w;
     }
     WorkItem fwd_head(const Mod& md, bool with_z) {
@@ -507,6 +508,7 @@ struct Builder {
         WorkItem w = gemm_item(loss ? K_FWD_OUT_LOSS : K_FWD_OUT_STORE, B, md.n_in, K_of(md.outl.in + 1), p<void>(in.rm), in.ld,
                                p<void>(md.outl.Wt), md.outl.ldt);
         w.binary = h->cfg.mod[m].binary ? 1 : 0;
+        if (loss && !md.conv) { w.kin = md.outl.in; w.aux1 = p<unsigned char>(md.outl.W) + (size_t)md.outl.in * md.outl.ld * h->es; w.ld1 = md.outl.ld; }
         const float bg = (float)(h->cfg.batch_global > 0 ? h->cfg.batch_global : h->cfg.batch_size);
         if (loss) {
             w.scale = w.binary ? h->cfg.mod[m].weight / bg : h->cfg.mod[m].weight;
@@ -739,8 +741,22 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         }
         if (nt && t <= 256) L.cfg = 4;
     }
+    if (L.cfg == 1 && !std::getenv("AVAE_NO_LOSS8")) {      // the output + loss launch of the big nets: 256x64 tiles, 8 waves, register epilogue
+        long t = 0;
+        bool loss_only = true;
+        for (int i = first; i < first + count; ++i) {
+            const WorkItem& w = items[i];
+            if (is_gemm(w.kind)) { loss_only = loss_only && w.kind == K_FWD_OUT_LOSS; t += (long)((w.M + 255) / 256) * ((w.N + 63) / 64); }
+        }
+        if (loss_only && t >= 192) L.cfg = 6;
+    }
     const int T = (L.cfg == 1 || L.cfg == 2 || L.cfg == 4) ? 128 : L.cfg == 5 ? 32 : 64;
-    const int TM = L.cfg == 2 ? 256 : (L.cfg == 3 || L.cfg == 5) ? 32 : L.cfg == 4 ? 64 : T;
+    const int TM = (L.cfg == 2 || L.cfg == 6) ? 256 : (L.cfg == 3 || L.cfg == 5) ? 32 : L.cfg == 4 ? 64 : T;
+    if ((L.cfg == 2 || L.cfg == 6) && !std::getenv("AVAE_NO_BIAS_EP"))      // 8-wave NT tiles: bias in the epilogue where that saves a K tile
+        for (int i = first; i < first + count; ++i) {
+            WorkItem& w = items[i];
+            if ((w.kind == K_FWD_HIDDEN || w.kind == K_FWD_OUT_LOSS) && w.kin > 0 && w.kin % h->KU == 0 && w.K == w.kin + h->KU) { w.K = w.kin; w.bias_ep = 1; }
+        }
     int max_tiles = 1;
     for (int i = first; i < first + count; ++i) {
         WorkItem& w = items[i];
@@ -854,6 +870,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         L.args.grid_x = L.grid_x;
         for (int i = 0; i < count; ++i) L.args.items[i] = items[first + i];
     }
+    if (const char* e = std::getenv("AVAE_SCHED")) L.args.sched = L.targs.sched = std::atoi(e);
     if (*next_slot > h->n_partial) throw Err("internal error: cost partial slots overflow");
     return L;
 }
@@ -1157,6 +1174,30 @@ void build_training_plan(avae_handle* h) {
             if (base > 0) h->wgrad.push_back(L);
         }
     }
+    // ---- weight warm-up: a launch on the 8-wave NT tiles pulls the weight panels of the next grouped NT launch into the Infinity
+    // Cache (see k_grouped); forward and backward form one sequence (the step graph runs them back to back)
+    if (!std::getenv("AVAE_NO_WARM")) {
+        std::vector<Launch*> seq;
+        for (Launch& L : h->fwd) seq.push_back(&L);
+        for (Launch& L : h->bwd) seq.push_back(&L);
+        for (size_t i = 0; i < seq.size(); ++i) {
+            Launch& L = *seq[i];
+            if (L.type != 0 || L.tn || (L.cfg != 2 && L.cfg != 6)) continue;
+            for (size_t j = i + 1; j < seq.size(); ++j) {
+                const Launch& Nx = *seq[j];
+                if (Nx.type != 0) continue;                 // helper launches of the conv branch in between
+                if (Nx.tn) break;
+                for (int k = 0; k < Nx.args.n_items && L.args.n_pf < kMaxPf; ++k) {
+                    const WorkItem& w = Nx.args.items[k];
+                    if (!is_gemm(w.kind) || w.kind == K_WGRAD) continue;
+                    const long bytes = (long)w.N * w.ldb * h->es;          // B = weight shadow: N rows of ldb elements
+                    if (bytes < 128 * 1024) continue;                     // small panels come with the first tile anyway
+                    L.args.pf_ptr[L.args.n_pf] = w.B; L.args.pf_lines[L.args.n_pf] = (int)(bytes / 128); ++L.args.n_pf;
+                }
+                break;
+            }
+        }
+    }
     // ---- eval: forward launches + a lone cost reduction that does not bump the step
     {
         const int first = (int)h->items.size();
@@ -1265,7 +1306,12 @@ struct Timed {
 
 void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, int stamp_base = -1) {
     int k = 0;
-    for (const Launch& L : ls) {
+    static const char* dup = std::getenv("AVAE_DUP");      // diagnostics: run the named launch twice, the second one timed as "<name>_again"
+    for (const Launch& L0 : ls) {
+      for (int rep = 0; rep < ((dup && h->timing && L0.name == dup) ? 2 : 1); ++rep) {
+        Launch Lr;
+        if (rep) { Lr = L0; Lr.name += "_again"; }
+        const Launch& L = rep ? Lr : L0;
         Timed t(h, s, L.name);
         unsigned long long* stamps = nullptr;
 #ifdef AVAE_STAMPS
@@ -1297,6 +1343,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
             std::fflush(stderr);
             HIP_OK(hipStreamSynchronize(s));
         }
+      }
         ++k;
     }
 }
