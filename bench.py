@@ -99,6 +99,10 @@ def launch_work(archs, B, es):
         out[name] = (b0 + by, f0 + fl)
     P = 0
     wg = []                                   # (bytes, flops, params) per weight-gradient item, in launch order
+    # big nets run the latent item (KL + association terms) as a launch of its own (avae_host.hip::build_training_plan)
+    cd = lambda a, b: -(-a // b)
+    latent_alone = (sum(cd(B, 256) * cd(na["n_input"], 64) for na in archs) >= 192 and sum(cd(B, 128) * cd(na["n_input"], 128) for na in archs) >= 192
+                    and not any(na["n_input"] <= 64 for na in archs) and B > 64)
     for na in archs:
         enc, head, dec, outl = dense_layers(na)
         L = len(enc)
@@ -109,7 +113,7 @@ def launch_work(archs, B, es):
         add("fwd_head", (B * i + (i + 1) * o) * es + B * o * 4 + B * nz * (4 + es), 2 * B * (i + 1) * o)
         for k, (i, o) in enumerate(dec):
             add("fwd_dec%d" % (k + 1), (B * i + (i + 1) * o + B * o) * es, 2 * B * (i + 1) * o)
-        add("fwd_out_loss", B * (2 + 3) * nz * 4, 0)                             # latent item (rides in this launch): mulv in, static grads out
+        add("latent" if latent_alone else "fwd_out_loss", B * (2 + 3) * nz * 4, 0)   # latent item: mulv in, static grads out
         i, o = outl
         add("fwd_out_loss", (B * i + (i + 1) * o + B * o) * es + B * o * 4, 2 * B * (i + 1) * o)
 

@@ -135,7 +135,7 @@ struct AdamItem {
     int rows, cols;          // in+1, out
     int ld, ldt;
     int tiles_r, tiles_c, tile_base;
-    int pad;
+    int ldw;                 // leading dim of the W shadow (>= ld: see spread_ld in avae_host.hip)
 };
 
 constexpr int kMaxAdamItems = 80;      // kMaxMod * (2*AVAE_MAX_HIDDEN + 2)

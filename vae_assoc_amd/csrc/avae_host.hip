@@ -65,7 +65,8 @@ struct Bump {
 
 struct Dense {             // one dense layer, weights + bias as W_aug [(in+1)][ld]
     int in = 0, out = 0;
-    int ld = 0;            // master / W-shadow leading dim = rup(out, KU)
+    int ld = 0;            // master (theta, m, v, g) leading dim = rup(out, KU)
+    int ldw = 0;           // W-shadow leading dim: ld, or ld + KU where ld would be a channel-aliasing stride (spread_ld)
     int ldt = 0;           // W^T-shadow leading dim = rup(in+1, KU)
     size_t master = 0;     // offset in floats inside the theta/m/v/g regions
     size_t W = 0, Wt = 0;  // byte offsets in the workspace
@@ -196,12 +197,20 @@ struct avae_handle {
 
 namespace {
 
+// Row strides that are a multiple of 512 bytes put the rows of an operand tile (one 128-byte chunk per row and K step) on a
+// handful of the L2's address-interleaved channels (a 2048-byte stride: C4's W shadows, 1024 x bf16 -- its dgrad K loop ran
+// 1.03 us per tile against 0.90 for the forward's 2176-byte rows).  One more K unit (128 bytes) of zero padding per row avoids it.
+inline int spread_ld(int ld, int KU, int es) {
+    static const bool off = std::getenv("AVAE_NO_LD_SPREAD") != nullptr;
+    return (!off && ((size_t)ld * es) % 512 == 0) ? ld + KU : ld;
+}
+
 Act make_act(Bump& b, int width, bool ones, int rows, int KU, int es, int ld = 0) {
     Act a;
     a.width = width;
     a.rows = rows;
     a.ones = ones;
-    a.ld = ld > 0 ? ld : (int)rup(width + 1, KU);       // ld given: a buffer that is never a GEMM operand
+    a.ld = ld > 0 ? ld : spread_ld((int)rup(width + 1, KU), KU, es);       // ld given: a buffer that is never a GEMM operand
     a.rm = b.take(rup(rows, kRowAlign) * (size_t)a.ld * es);
     return a;
 }
@@ -210,10 +219,11 @@ Dense make_dense(Bump& b, size_t& pint, int in, int out, int KU, int es, bool he
     Dense d;
     d.in = in; d.out = out; d.head = head;
     d.ld = (int)rup(out, KU);
-    d.ldt = (int)rup(in + 1, KU);
+    d.ldw = spread_ld(d.ld, KU, es);
+    d.ldt = spread_ld((int)rup(in + 1, KU), KU, es);
     d.master = pint;
     pint += (size_t)(in + 1) * d.ld;
-    d.W = b.take(rup(in + 1, kRowAlign) * (size_t)d.ld * es);
+    d.W = b.take(rup(in + 1, kRowAlign) * (size_t)d.ldw * es);
     d.Wt = b.take(rup(out, kRowAlign) * (size_t)d.ldt * es);
     return d;
 }
@@ -491,7 +501,7 @@ struct Builder {
         WorkItem w = gemm_item(K_FWD_HIDDEN, B, d.out, K_of(d.in + 1), p<void>(in.rm), in.ld, p<void>(d.Wt), d.ldt);
         w.act = h->cfg.activation;
         w.out0 = p<void>(out.rm); w.ld0 = out.ld;
-        w.kin = d.in; w.aux1 = p<unsigned char>(d.W) + (size_t)d.in * d.ld * h->es; w.ld1 = d.ld;   // bias row (see WorkItem::bias_ep)
+        w.kin = d.in; w.aux1 = p<unsigned char>(d.W) + (size_t)d.in * d.ldw * h->es; w.ld1 = d.ldw;   // bias row (see WorkItem::bias_ep)
         return w;
     }
     WorkItem fwd_head(const Mod& md, bool with_z) {
@@ -508,7 +518,7 @@ struct Builder {
         WorkItem w = gemm_item(loss ? K_FWD_OUT_LOSS : K_FWD_OUT_STORE, B, md.n_in, K_of(md.outl.in + 1), p<void>(in.rm), in.ld,
                                p<void>(md.outl.Wt), md.outl.ldt);
         w.binary = h->cfg.mod[m].binary ? 1 : 0;
-        if (loss && !md.conv) { w.kin = md.outl.in; w.aux1 = p<unsigned char>(md.outl.W) + (size_t)md.outl.in * md.outl.ld * h->es; w.ld1 = md.outl.ld; }
+        if (loss && !md.conv) { w.kin = md.outl.in; w.aux1 = p<unsigned char>(md.outl.W) + (size_t)md.outl.in * md.outl.ldw * h->es; w.ld1 = md.outl.ldw; }
         const float bg = (float)(h->cfg.batch_global > 0 ? h->cfg.batch_global : h->cfg.batch_size);
         if (loss) {
             w.scale = w.binary ? h->cfg.mod[m].weight / bg : h->cfg.mod[m].weight;
@@ -521,7 +531,7 @@ struct Builder {
         return w;
     }
     WorkItem dgrad_hidden(const Act& dA, const Dense& d, const Act& yprev, const Act& dprev) {
-        WorkItem w = gemm_item(K_DGRAD_HIDDEN, B, d.in, K_of(d.out), p<void>(dA.rm), dA.ld, p<void>(d.W), d.ld);
+        WorkItem w = gemm_item(K_DGRAD_HIDDEN, B, d.in, K_of(d.out), p<void>(dA.rm), dA.ld, p<void>(d.W), d.ldw);
         w.act = h->cfg.activation;
         w.aux0 = p<void>(yprev.rm); w.ldx = yprev.ld;
         w.out0 = p<void>(dprev.rm); w.ld0 = dprev.ld;
@@ -530,7 +540,7 @@ struct Builder {
     WorkItem dgrad_latent(const Mod& md) {
         const Dense& d = md.dec[0];
         const Act& dA = md.dD[0];
-        WorkItem w = gemm_item(K_DGRAD_LATENT, B, h->nz, K_of(d.out), p<void>(dA.rm), dA.ld, p<void>(d.W), d.ld);
+        WorkItem w = gemm_item(K_DGRAD_LATENT, B, h->nz, K_of(d.out), p<void>(dA.rm), dA.ld, p<void>(d.W), d.ldw);
         w.nz = h->nz;
         w.aux2 = p<void>(md.g0);
         w.out0 = p<void>(md.dH.rm); w.ld0 = md.dH.ld;
@@ -545,7 +555,7 @@ struct Builder {
         return w;
     }
     WorkItem conv_dgrad(const ConvStage& st, const Act& dA) {          // fp32 patch gradients dP = dA . W^T
-        WorkItem w = gemm_item(K_DGRAD_F32, conv_rows(st), st.d.in, K_of(st.d.out), p<void>(dA.rm), dA.ld, p<void>(st.d.W), st.d.ld);
+        WorkItem w = gemm_item(K_DGRAD_F32, conv_rows(st), st.d.in, K_of(st.d.out), p<void>(dA.rm), dA.ld, p<void>(st.d.W), st.d.ldw);
         w.out0 = p<void>(st.dP); w.ld0 = st.lddp;
         return w;
     }
@@ -951,6 +961,22 @@ void build_training_plan(avae_handle* h) {
                       [&](Mod& md) { return h->at<void>(md.cenc[2].Y.rm); }, every_conv);
     }
     group("fwd_head", h->fwd, [&] { for (Mod& md : h->mods) h->items.push_back(bd.fwd_head(md, true)); });
+    // KL + association terms and their (mu, lv) gradients need every modality's (mu, lv) (ready after fwd_head) and are needed by
+    // bwd_dec1_latent.  Small nets: they ride in the fwd_out_loss launch (the decoder's hidden launches stay plain GEMM launches).
+    // Big nets, whose loss launch runs one 144-KB workgroup per CU on the 8-wave tile: there the item's workgroups would each take a
+    // CU's only slot and send the launch into a second round (C4: 512 workgroups, 33 us), so it gets a launch of its own here.
+    bool latent_alone = false;
+    {
+        long t64 = 0, t128 = 0;
+        bool narrow = false;
+        for (const Mod& md : h->mods) {
+            t64 += (long)((h->B + 255) / 256) * ((md.n_in + 63) / 64);
+            t128 += (long)((h->B + 127) / 128) * ((md.n_in + 127) / 128);
+            narrow = narrow || md.n_in <= 64 || h->B <= 64;
+        }
+        latent_alone = t64 >= 192 && t128 >= 192 && !narrow && !std::getenv("AVAE_NO_LOSS8");      // = finish_launch's choice of cfg 6
+    }
+    if (latent_alone) group("latent", h->fwd, [&] { h->items.push_back(bd.latent()); });
     for (int k = 0; k < std::max(Lmax, 1); ++k)
         group("fwd_dec" + std::to_string(k + 1), h->fwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k]));
@@ -996,9 +1022,7 @@ void build_training_plan(avae_handle* h) {
     }
     group("fwd_out_loss", h->fwd, [&] {
         for (int m = 0; m < h->M; ++m) h->items.push_back(bd.fwd_out(h->mods[m], m, true));
-        // KL + association terms and their (mu, lv) gradients: need every modality's (mu, lv) (ready after fwd_head) and are
-        // needed by bwd_dec1_latent; they ride here so that the decoder's hidden launches stay plain GEMM launches
-        h->items.push_back(bd.latent());
+        if (!latent_alone) h->items.push_back(bd.latent());
     });
     // ---- backward: the dgrad chain (one launch per layer, all modalities), then EVERY weight gradient in the last
     // launch(es), then k_adam.  Conv stages go GEMM (fp32 patch gradients) -> k_col2im (sum + act' -> gradient of the
@@ -1216,7 +1240,7 @@ void build_training_plan(avae_handle* h) {
         a.v = h->at<float>(h->off_v) + d.master;
         a.g = h->grad() + d.master;
         a.W = h->at<void>(d.W); a.Wt = h->at<void>(d.Wt);
-        a.rows = d.in + 1; a.cols = d.out; a.ld = d.ld; a.ldt = d.ldt;
+        a.rows = d.in + 1; a.cols = d.out; a.ld = d.ld; a.ldw = d.ldw; a.ldt = d.ldt;
         a.tiles_r = (a.rows + kAdamRows - 1) / kAdamRows; a.tiles_c = (a.cols + 63) / 64; a.tile_base = base;
         base += a.tiles_r * a.tiles_c;
         h->adam_items.push_back(a);

@@ -826,10 +826,7 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
         }
     } else {
     if (PREF && has_aux && nk < 2) load_aux();     // a single K tile: ahead of its DMA (vmcnt retires in order)
-    {
-        const int npro = nk < RING - 1 ? nk : RING - 1;
-        for (int p = 0; p < npro; ++p) AVAE_DMA(p, p)
-    }
+    const int npro = nk < RING - 1 ? nk : RING - 1;
     // Weight warm-up for the NEXT launch (8-wave NT tiles): its weight panels were last written by k_adam half a step ago and have
     // left the Infinity Cache; fetched cold they cost that launch 2.5-3 us (a launch repeated right away, its operands warm, ran
     // 23.0 -> 20.1 us).  Every wave touches one dword of n_pf x 64 of their 128-byte lines -- after tile 0's wait, so the first
@@ -838,12 +835,29 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
     int n_pf = 0;
     unsigned pf_v[kMaxPf] = {0u, 0u, 0u, 0u};     // destinations of the warm-up loads: read only after the loop's last wait, so the
                                                   // registers stay reserved while the loads are in flight
-    if constexpr (REGEP && RING == 3) n_pf = nk >= 3 ? args.n_pf : 0;
+    if constexpr (REGEP && RING == 3) n_pf = args.n_pf;
+    const bool pf_early = nk < 3;                 // short K loops: ahead of everything (the first wait then covers them)
+    auto warm_next = [&]() {
+      if constexpr (REGEP && RING == 3) {
+        const unsigned nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned idx = (unsigned)tid * nwg + wg;          // lines dealt round-robin over the workgroups
+#pragma unroll
+        for (int r = 0; r < kMaxPf; ++r)
+            if (r < n_pf) {          // every lane loads (out-of-range lanes re-read the last line): exactly one instruction per wave and range
+                const unsigned char* p = reinterpret_cast<const unsigned char*>(args.pf_ptr[r]) + (size_t)min(idx, (unsigned)args.pf_lines[r] - 1u) * 128u;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(pf_v[r]) : "v"(p));
+            }
+      }
+    };
+    {
+        if constexpr (REGEP && RING == 3) { if (n_pf > 0 && pf_early) warm_next(); }
+        for (int p = 0; p < npro; ++p) AVAE_DMA(p, p)
+    }
     int buf = 0;                               // stage of tile kt; the refill goes to the stage freed by tile kt-1
     for (int kt = 0; kt < nk; ++kt) {
         AVAE_LT0()
         // last tile: the epilogue's operand (issued behind the last refill) may still be on its way
-        if (REGEP && RING == 3 && kt == 1 && n_pf > 0) {
+        if (REGEP && RING == 3 && kt == 1 && n_pf > 0 && !pf_early) {
             if (n_pf == 1) AVAE_WAIT(NCH + 1); else if (n_pf == 2) AVAE_WAIT(NCH + 2); else if (n_pf == 3) AVAE_WAIT(NCH + 3); else AVAE_WAIT(NCH + 4);
         } else
         AVAE_WAIT_TILE(nk - 1 - kt, if (PREF && aux_inflight) AVAE_WAIT(NAUX); else AVAE_WAIT(0))
@@ -851,18 +865,7 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
         asm volatile("s_barrier" ::: "memory");
         AVAE_LT(1)
         if (kt == 0) { AVAE_STAMP(2) }
-        if constexpr (REGEP && RING == 3) {
-            if (kt == 0 && n_pf > 0) {
-                const unsigned nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
-                const unsigned idx = (unsigned)tid * nwg + wg;          // lines dealt round-robin over the workgroups
-#pragma unroll
-                for (int r = 0; r < kMaxPf; ++r)
-                    if (r < n_pf) {          // every lane loads (out-of-range lanes re-read the last line): exactly one instruction per wave and range
-                        const unsigned char* p = reinterpret_cast<const unsigned char*>(args.pf_ptr[r]) + (size_t)min(idx, (unsigned)args.pf_lines[r] - 1u) * 128u;
-                        asm volatile("global_load_dword %0, %1, off" : "=v"(pf_v[r]) : "v"(p));
-                    }
-            }
-        }
+        if constexpr (REGEP && RING == 3) { if (kt == 0 && n_pf > 0 && !pf_early) warm_next(); }
         if constexpr (PREF) {
             static_assert(!PREF || RING == 3, "the aux prefetch is placed for a 3-stage ring: no refill is issued in the last two iterations");
             if (has_aux && nk >= 2 && kt == nk - 2) { load_aux(); aux_inflight = true; }
@@ -1235,7 +1238,9 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
     static_assert(TR % 16 == 0 && TR <= 64, "a pass covers 16 rows x 16 quads");
     constexpr int NTH = kThreads;
     __shared__ float T[TR][65];
-    const int bid = blockIdx.x, tid = threadIdx.x;
+    // Tiles are taken LAST FIRST: the launch streams 32 bytes per parameter through the Infinity Cache (256 MiB), so what it
+    // touches last is what the next step's first launches find there -- the encoders' weight shadows, not the decoders'.
+    const int bid = (int)gridDim.x - 1 - (int)blockIdx.x, tid = threadIdx.x;
     int it = 0;
     for (int i = 1; i < a.n_items; ++i)
         if (bid >= a.base[i]) it = i;                       // kernel-argument table, ascending
@@ -1277,7 +1282,7 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
                 store_row<float>(w.m + off, m, nv);
                 store_row<float>(w.v + off, v, nv);
             }
-            store_row<CT>(reinterpret_cast<CT*>(w.W) + off, th, w.cols - gcol);
+            store_row<CT>(reinterpret_cast<CT*>(w.W) + (size_t)grow * w.ldw + gcol, th, w.cols - gcol);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) T[r][c4 + e] = th[e];
