@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_arch, synth_batch
+from conftest import GOLDEN, make_arch, synth_batch
 from oracle import vae_assoc_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -177,6 +177,110 @@ def test_golden_fixture(V, golden, name, dtype):
             assert np.abs(rec[m][:16] - G["rec%d" % m]).max() <= 1e-4
         ce = model.evaluate_cost(X, G["eps"][2])
         assert abs(ce - G["eval_cost3"]) <= 1e-4 * abs(G["eval_cost3"])
+
+
+def _load_big():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_big", os.path.join(GOLDEN, "make_golden_big.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _check_sampled(G, tag, got, what, tol, noise=0.0):
+    """HIP tensor set `got` (flat) against the fixture's per-tensor maxima / norms / sampled entries of run `tag`.
+    `noise` > 0 (bf16 runs of deep relu nets): the bound of a tensor is max(tol, noise x d), d = the distance between the fixture's
+    own bf16-rounding and fp64 runs on that tensor -- two runs that round to bf16 at the same points but accumulate differently
+    (fp32 MFMA vs fp64) flip the rounding of some activations by one ulp and the relu decision of pre-activations near 0, and what
+    that does to a tensor's gradient scales with that tensor's sensitivity to bf16 rounding, which d measures."""
+    ptr, idx = G["sample_ptr"], G["sample_idx"]
+    bad = []
+    for t, name in enumerate(G["names"]):
+        sl = slice(int(ptr[t]), int(ptr[t + 1]))
+        mx = max(float(G[what + "max_" + tag][t]), 1e-30)
+        err = float(np.abs(got[idx[sl]] - G[what + "sample_" + tag][sl]).max()) / mx
+        bound = tol
+        if noise > 0.0:
+            bound = max(tol, noise * float(np.abs(G[what + "sample_bf16"][sl] - G[what + "sample_f64"][sl]).max()) / mx)
+        if err > bound:
+            bad.append((str(name), "sample", err, bound))
+    return bad
+
+
+def test_c4_full_size_gradients(V):
+    """BASELINE C4 at the BENCHMARK size (4 x 1024 hidden, n_z = 64, batch 4096, bf16) against the committed
+    fixture of the oracle run at that size (tests/golden/c4_b4096.npz, made by make_golden_big.py): cost, posterior statistics and
+    every tensor's gradient -- maxima, L2 norms and 1024 sampled entries per tensor.  This is the plan the bench times: 256x128
+    8-wave tiles with the register epilogue, bias folded into the epilogue, 256x64 loss tiles, the 20-item XCD-packed
+    weight-gradient launch on producer waves, 64x128 head tiles."""
+    big = _load_big()
+    G = np.load(os.path.join(GOLDEN, "c4_b4096.npz"), allow_pickle=False)
+    c = big.C4
+    X, eps, p0 = big.c4_inputs()
+    chk = [float(X[0].astype(np.float64).sum()), float(X[1].astype(np.float64).sum()), float(eps.astype(np.float64).sum()), float(p0.astype(np.float64).sum())]
+    assert np.allclose(chk, G["checksum"], rtol=1e-12), "the seeded inputs are not the ones the fixture was made from"
+    # 1) softplus, strict: the same plan (tile shapes, launch tables, XCD packing; the transfer function changes no launch) without
+    # relu's kink -- with relu and 33 M hidden pre-activations per pass a few land within rounding of 0 and flip their derivative
+    # between two arithmetic types: measured on the fp32 kernels against the fp64 run, ONE of 1024 sampled entries of dec_b4 /
+    # dec_b3 off by 1e-3 of the tensor maximum (one sample's contribution), the rest at 1e-6 (tools/c4_grad_diag.py).
+    # fp32 operands on the exact-fp32 MFMA kernels against the fp64 run, bf16 operands against the bf16-rounding run.
+    for dtype, tag, ctol, gtol in (("fp32", "f64_softplus", 1e-5, 1e-4), ("bf16", "bf16_softplus", 5e-5, 3e-3)):
+        m = V.AssocVariationalAutoEncoder(c["archs"], binary=c["binary"], transfer_fct="softplus", weights=c["weights"],
+                                          assoc_lambda=c["assoc_lambda"], learning_rate=c["lr"], batch_size=c["B"], compute_dtype=dtype)
+        m.set_params(p0)
+        cost = m.partial_fit(X, eps)
+        assert abs(cost - float(G["cost_" + tag])) <= ctol * abs(cost), (dtype, cost, float(G["cost_" + tag]))
+        bad = _check_sampled(G, tag, m.get_grads().astype(np.float64), "g", gtol)
+        assert not bad, (dtype, bad)
+        del m
+    # 2) relu = the benchmark configuration itself, bf16: cost at both tolerances, gradients within the noise-aware bound
+    m = V.AssocVariationalAutoEncoder(c["archs"], binary=c["binary"], transfer_fct=c["act"], weights=c["weights"], assoc_lambda=c["assoc_lambda"],
+                                      learning_rate=c["lr"], batch_size=c["B"], compute_dtype="bf16")
+    assert m.n_params == 14900387
+    m.set_params(p0)
+    cost = m.partial_fit(X, eps)
+    assert abs(cost - float(G["cost_bf16"])) <= 5e-5 * abs(cost), (cost, float(G["cost_bf16"]))        # like-for-like oracle
+    assert abs(cost - float(G["cost_f64"])) <= 1e-3 * abs(cost), (cost, float(G["cost_f64"]))           # north_star: 1e-3 of the fp64 run
+    g = m.get_grads().astype(np.float64)
+    bad = _check_sampled(G, "bf16", g, "g", 3e-3, noise=0.5)
+    assert not bad, bad
+    off = 0
+    for t, (name, shp) in enumerate([(n, s) for na in c["archs"] for n, s in O.layer_shapes(na)]):
+        n = int(np.prod(shp))
+        l2, want = float(np.linalg.norm(g[off:off + n])), float(G["gl2_bf16"][t])
+        assert abs(l2 - want) <= 5e-3 * want, (name, l2, want)
+        assert abs(float(np.abs(g[off:off + n]).max()) - float(G["gmax_bf16"][t])) <= 1e-2 * float(G["gmax_bf16"][t]), name
+        off += n
+    for k in range(2):
+        mulv = fetch(m, "mulv%d" % k, (c["B"], 128))[:64]
+        assert np.abs(mulv[:, :64] - G["mu%d_bf16" % k]).max() <= 2e-3 * max(1.0, np.abs(G["mu%d_bf16" % k]).max())
+        assert np.abs(mulv[:, 64:] - G["lv%d_bf16" % k]).max() <= 2e-3 * max(1.0, np.abs(G["lv%d_bf16" % k]).max())
+        assert np.abs(mulv[:, :64] - G["mu%d_f64" % k]).max() <= 2e-2 * max(1.0, np.abs(G["mu%d_f64" % k]).max())
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["conv_small", "c5_small"])
+def test_round2_small_fixtures(V, name, dtype):
+    """Committed fixtures for the conv/deconv branch and for the 3-modality (C5) net: cost, gradients (sampled entries of every
+    tensor) and two Adam steps against the oracle outputs stored in tests/golden/."""
+    big = _load_big()
+    G = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    c, X, eps, p0 = big.small_inputs(name)
+    fp32 = dtype == "fp32"
+    tag = "f64" if fp32 else "bf16"
+    m = V.AssocVariationalAutoEncoder(c["archs"], binary=c["binary"], transfer_fct=c["act"], weights=c["weights"], assoc_lambda=c["assoc_lambda"],
+                                      learning_rate=c["lr"], batch_size=c["B"], compute_dtype=dtype)
+    m.set_params(p0)
+    costs = [m.partial_fit(X, eps[0])]
+    assert abs(costs[0] - float(G["cost0_" + tag])) <= (1e-5 if fp32 else 5e-5) * abs(costs[0])
+    bad = _check_sampled(G, tag, m.get_grads().astype(np.float64), "g", 1e-4 if fp32 else 3e-3)
+    assert not bad, bad
+    costs.append(m.partial_fit(X, eps[1]))
+    assert np.allclose(costs, G["costs_" + tag], rtol=2e-5 if fp32 else 3e-4)
+    if not fp32:
+        assert np.allclose(costs, G["costs_f64"], rtol=1e-2)       # (small nets, few terms: the 1e-3 bound is for the reference configs)
+    p2 = m.get_params().astype(np.float64)
+    assert np.abs(p2[G["sample_idx"]] - G["p2sample_" + tag]).max() <= (2e-4 if fp32 else 5e-3)
 
 
 # ----------------------------------------------------------------------------- full reference sizes

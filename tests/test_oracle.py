@@ -2,12 +2,13 @@
 autograd transcription of the reference's loss, (2) central finite differences, (3) closed-form
 spot checks from SURVEY.md 8c, and (4) the committed golden fixtures."""
 import itertools
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import make_arch, synth_batch
+from conftest import GOLDEN, make_arch, synth_batch
 from oracle import vae_assoc_oracle as O
 
 
@@ -251,3 +252,46 @@ def test_oracle_reproduces_golden(golden, name):
                            dtype=np.float32, params_flat=G["params0"])
     c32, _, _ = m32.cost_and_grads(X, G["eps"][0])
     assert abs(c32 - G["cost0"]) <= 1e-5 * abs(G["cost0"])
+
+
+# ----------------------------------------------------------------------------- round-2 fixtures (sampled gradients)
+def _load_big():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_big", os.path.join(GOLDEN, "make_golden_big.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("name", ["conv_small", "c5_small"])
+def test_oracle_reproduces_round2_small_fixtures(name):
+    """conv/deconv branch and the 3-modality net: the committed fixtures pin the oracle on those branches against silent edits
+    (cost, per-tensor gradient maxima / norms / sampled entries, weights after two Adam steps), fp64 and bf16-emulating runs."""
+    big = _load_big()
+    G = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    c, X, eps, p0 = big.small_inputs(name)
+    chk = [float(x.astype(np.float64).sum()) for x in X] + [float(eps.astype(np.float64).sum()), float(p0.astype(np.float64).sum())]
+    assert np.allclose(chk, G["checksum"], rtol=1e-12), "the seeded inputs are not the ones the fixture was made from"
+    for tag, quant in (("f64", None), ("bf16", "bf16")):
+        m = O.OracleAssocVAE(c["archs"], c["binary"], c["act"], c["weights"], c["assoc_lambda"], c["lr"], c["B"],
+                             params_flat=p0.astype(np.float64), quant=quant)
+        cost, g, fw = m.cost_and_grads(X, eps[0])
+        assert abs(cost - float(G["cost0_" + tag])) <= 1e-10 * abs(cost)
+        assert np.allclose(g[G["sample_idx"]], G["gsample_" + tag], rtol=1e-9, atol=1e-12)
+        costs = [m.partial_fit(X, eps[s]) for s in range(2)]
+        assert np.allclose(costs, G["costs_" + tag], rtol=1e-10)
+        assert np.allclose(m.get_params()[G["sample_idx"]], G["p2sample_" + tag], rtol=1e-9, atol=1e-12)
+
+
+def test_oracle_reproduces_c4_fixture():
+    """BASELINE C4 at its full size (4 x 1024, n_z = 64, batch 4096): ~6 s of fp64 BLAS here."""
+    big = _load_big()
+    G = np.load(os.path.join(GOLDEN, "c4_b4096.npz"), allow_pickle=False)
+    c = big.C4
+    X, eps, p0 = big.c4_inputs()
+    chk = [float(X[0].astype(np.float64).sum()), float(X[1].astype(np.float64).sum()), float(eps.astype(np.float64).sum()), float(p0.astype(np.float64).sum())]
+    assert np.allclose(chk, G["checksum"], rtol=1e-12)
+    m = O.OracleAssocVAE(c["archs"], c["binary"], c["act"], c["weights"], c["assoc_lambda"], c["lr"], c["B"], params_flat=p0.astype(np.float64))
+    cost, g, _fw = m.cost_and_grads(X, eps)
+    assert abs(cost - float(G["cost_f64"])) <= 1e-10 * abs(cost)
+    assert np.allclose(g[G["sample_idx"]], G["gsample_f64"], rtol=1e-8, atol=1e-12)
