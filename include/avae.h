@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AVAE_ABI_VERSION 2
+#define AVAE_ABI_VERSION 3
 #define AVAE_MAX_MODALITIES 4
 #define AVAE_MAX_HIDDEN 8
 
@@ -77,6 +77,18 @@ typedef struct avae_config {
     uint64_t seed;                      /* Philox key of the internal eps generator */
     void* workspace;                    /* optional caller-owned device memory (>= avae_workspace_bytes); NULL -> hipMalloc */
     size_t workspace_bytes;
+    /* Library-owned gradient collective (the reference is single-process, vae_assoc.py:66).  use_comm = 1:
+     * avae_create builds an RCCL communicator of world_size ranks from nccl_id (the 128 bytes of an ncclUniqueId made by
+     * avae_comm_unique_id on rank 0 and handed to every rank by whatever bootstrap the host has -- torch.distributed here);
+     * avae_train_step(s) then run backward -> ncclAllReduce -> Adam per bucket on the library's own streams, the all-reduce of
+     * the decoder-side bucket overlapping the encoder's backward pass.  use_comm = 0: no communicator; a host that owns the
+     * collective drives the same buckets through avae_dp_backward / avae_dp_apply (or the unbucketed avae_step_backward /
+     * avae_step_apply seam).  batch_global / row_offset above stay the caller's to set (world_size*batch_size, rank*batch_size). */
+    int32_t use_comm;
+    int32_t world_size;
+    int32_t rank;
+    int32_t reserved2;
+    uint8_t nccl_id[128];
 } avae_config;
 
 typedef struct avae_handle avae_handle;
@@ -130,6 +142,17 @@ int avae_stage_batches(avae_handle* h, int32_t n_steps, const float* const* x_de
                        const float* eps_dev, void* stream);
 int avae_step_backward_staged(avae_handle* h, int32_t j, void* stream);
 int avae_grad_buffer(avae_handle* h, float** dev_ptr, size_t* n_floats);
+/* ---- bucketed data-parallel step.  Bucket 0 = decoder side of every modality (+ the cost slot), bucket 1 = encoder side; models
+ * with a conv modality have the single bucket 0.  Each bucket is a few contiguous float ranges of the gradient buffer.
+ * avae_dp_plan is host-only (no GPU needed): ranges of the configuration's buckets, offs/counts hold up to
+ * 2*AVAE_MAX_MODALITIES entries, n_ranges[b] of them belong to bucket b (bucket 0 first).
+ * Host-owned collective:  avae_stage_batches(n) ; per step j:  avae_dp_backward(j, 0) -> all-reduce bucket 0's ranges ->
+ * avae_dp_backward(j, 1) -> all-reduce bucket 1's ranges -> avae_dp_apply(0) -> avae_dp_apply(1). */
+int avae_dp_plan(const avae_config* cfg, int32_t* n_buckets, int32_t* n_ranges, int64_t* offs, int64_t* counts);
+int avae_dp_backward(avae_handle* h, int32_t j, int32_t bucket, void* stream);
+int avae_dp_apply(avae_handle* h, int32_t bucket, float* cost_host, void* stream);
+/* 128 bytes of a fresh ncclUniqueId (rank 0 calls this; every rank passes the same bytes in avae_config.nccl_id). */
+int avae_comm_unique_id(void* id128);
 /* Costs of the most recent `n` applied steps (oldest first), without having synchronised per step. */
 int avae_cost_history(avae_handle* h, int32_t n, float* host_dst, int64_t* last_step);
 

@@ -111,3 +111,43 @@ def test_bench_accounting_matches_survey_figures():
         assert P == (1468611 if cfg == "c2" else 14900387)
         # every launch name bench prices is a launch the library reports (names mirror build_training_plan)
         assert {"prep", "adam", "fwd_head", "fwd_out_loss", "bwd_out", "bwd_dec1_latent", "bwd_head"} <= set(work)
+
+
+def test_dp_plan_is_host_only_and_tiles_the_gradient_buffer(capi):
+    """avae_dp_plan (no GPU needed): the data-parallel buckets of a configuration.  MLP models: bucket 0 = decoder side of every
+    modality + the cost slot, bucket 1 = encoder side; the ranges are disjoint and tile [0, P_int + 1) exactly, and P_int carries
+    at most 3 floats of padding per matrix row over the reference's parameter count (the wire carries no K padding).  A conv
+    modality: one bucket."""
+    L = capi.lib()
+
+    def plan(cfg):
+        nb, nr = C.c_int32(0), (C.c_int32 * 2)()
+        offs, cnts = (C.c_int64 * 8)(), (C.c_int64 * 8)()
+        assert L.avae_dp_plan(C.byref(cfg), C.byref(nb), nr, offs, cnts) == 0
+        out, k = [], 0
+        for b in range(2):
+            out.append([(int(offs[k + i]), int(cnts[k + i])) for i in range(nr[b])])
+            k += nr[b]
+        return nb.value, out
+    nb, (b0, b1) = plan(_config(capi, B=256))
+    assert nb == 2 and len(b0) == 2 and len(b1) == 2
+    spans = sorted(b0 + b1)
+    assert spans[0][0] == 0
+    for (o0, c0), (o1, _c1) in zip(spans, spans[1:]):
+        assert o0 + c0 == o1, "ranges must tile the buffer without gaps or overlap"
+    total = spans[-1][0] + spans[-1][1]            # = P_int + 1 (cost slot)
+    P = 1468611
+    rows = 2 * (785 + 501 + 501 + 21 + 501 + 501) + 0  # matrix rows of img; jnt below
+    rows = (785 + 501 + 501 + 21 + 501 + 501) + (148 + 201 + 201 + 21 + 201 + 201)
+    assert P + 1 <= total <= P + 1 + 3 * rows
+    assert (total - 1) * 4 < 1.01 * P * 4           # C2: 5.89 MB on the wire for 5.87 MB of parameters
+    # encoder side of modality 0 starts the buffer; the decoder side of the LAST modality ends it and carries the cost
+    assert b1[0][0] == 0 and b0[-1][0] + b0[-1][1] == total
+    enc0 = 785 * 500 + 501 * 500 + 501 * 40
+    assert b1[0][1] == enc0                          # 500- and 40-wide rows need no padding to 4 floats
+    cfg = _config(capi, B=64)
+    cfg.mod[0].hidden_conv = 1
+    cfg.mod[0].n_hidden[0], cfg.mod[0].n_hidden[1] = 8, 16
+    cfg.mod[0].conv_gener[0], cfg.mod[0].conv_gener[1] = 16, 8
+    nb, (b0, b1) = plan(cfg)
+    assert nb == 1 and len(b0) == 1 and b1 == [] and b0[0][0] == 0

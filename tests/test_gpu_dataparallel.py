@@ -146,9 +146,10 @@ def test_train_under_data_parallel_equals_global_batch_run(tmp_path):
 
 
 def test_rccl_backend_collective_on_the_gradient_view():
-    """The collective the data-parallel path issues, on the RCCL backend (one rank is all a one-GPU box offers):
-    backward graph -> dist.all_reduce of the float32 view into the library's workspace -> Adam, over a run of steps,
-    leaves the weights bitwise equal to the single-replica run (tools/nccl_view_check.py, in a process of its own)."""
+    """The gradient collective on the RCCL backend (one rank is all a one-GPU box offers), tools/nccl_view_check.py in a process
+    of its own: (a) the library-owned communicator (ncclCommInitRank inside avae_create, ncclAllReduce per bucket on the
+    library's comm stream, Adam per bucket) and (b) torch.distributed.all_reduce over the same buckets both leave weights and
+    costs bitwise equal to the single-replica run."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -159,4 +160,23 @@ def test_rccl_backend_collective_on_the_gradient_view():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_view_check.py")], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "weights equal to the single-replica run: True" in r.stdout
+    assert "library-owned RCCL communicator: weights and costs equal to the single-replica run: True" in r.stdout
+    assert "torch-owned collective over the same buckets: weights and costs equal to the single-replica run: True" in r.stdout
+
+
+def test_library_comm_without_process_group():
+    """comm='library' with no torch.distributed at all: a one-rank communicator (ncclUniqueId drawn and consumed locally) -- the
+    C ABI's collective has no dependency on torch; 3 single steps + a run of 18 are bitwise the plain run's."""
+    import __graft_entry__ as g
+    g.build()
+    from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+    rng = np.random.default_rng(5)
+    X = synth_batch(rng, 18 * B_LOC, [784, 147], [True, False])
+    res = []
+    for comm in (None, "library"):
+        m = AssocVariationalAutoEncoder(ARCHS, batch_size=B_LOC, compute_dtype="bf16", device=0, comm=comm, **KW)
+        assert m._comm_lib == (comm == "library")
+        costs = [m.partial_fit([x[i * B_LOC:(i + 1) * B_LOC] for x in X]) for i in range(3)]
+        m.partial_fit_steps(X, 18, return_cost=False)
+        res.append((costs, m.cost_history(21).copy(), m.get_params()))
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])

@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 
 from conftest import make_arch, synth_batch
 from oracle import vae_assoc_oracle as O
-from vae_assoc_amd.parallel import GradSync, dp_train_step
+from vae_assoc_amd.parallel import GradSync, dp_train_step, dp_train_step_bucketed
 
 ARCHS = [make_arch("image", 60, 20, 16, 5), make_arch("joint", 21, 12, 10, 5)]
 BIN, W, LAM, LR = [True, False], [50.0, 1.0], 8.0, 1e-3
@@ -42,6 +42,39 @@ class OracleReplica(object):
         return float(self.flat[-1])
 
 
+def oracle_buckets():
+    """[decoder-side ranges, encoder-side ranges] in the ORACLE's flat layout (the library's own ranges, in its internal layout,
+    come from avae_dp_plan): per modality [enc..., heads | dec..., out], the cost slot after the last range of bucket 0."""
+    b0, b1, off = [], [], 0
+    for na in ARCHS:
+        n_enc = sum(int(np.prod(s)) for n, s in O.layer_shapes(na) if n.startswith("enc_"))
+        n_dec = sum(int(np.prod(s)) for n, s in O.layer_shapes(na) if n.startswith("dec_"))
+        b1.append((off, n_enc))
+        b0.append((off + n_enc, n_dec))
+        off += n_enc + n_dec
+    b0[-1] = (b0[-1][0], b0[-1][1] + 1)
+    return [b0, b1]
+
+
+class BucketedReplica(OracleReplica):
+    """the bucketed seam of parallel.dp_train_step_bucketed on the CPU oracle: a bucket's ranges are published by its backward part"""
+
+    def _stage(self, X, eps):
+        self._X, self._eps = X, eps
+        self.flat.zero_()
+
+    def _backward_bucket(self, b):
+        c, g, _ = self.model.cost_and_grads(self._X, self._eps, batch_global=self.batch_global)
+        full = np.concatenate([g, [c]])
+        for off, cnt in oracle_buckets()[b]:
+            self.flat[off:off + cnt] = torch.from_numpy(full[off:off + cnt])
+
+    def _apply_bucket(self, b, want_cost):
+        if b == 1:                      # Adam is element-wise: applying per bucket = applying once all buckets have arrived
+            self.model.apply_gradients(self.flat[:-1].numpy())
+        return float(self.flat[-1]) if want_cost else None
+
+
 def _data():
     rng = np.random.default_rng(31)
     X = synth_batch(rng, B_GLOBAL, [a["n_input"] for a in ARCHS], BIN)
@@ -62,6 +95,13 @@ def _worker(rank, port, out_dir):
         rep = OracleReplica(bl, B_GLOBAL, p0)
         costs = [dp_train_step(rep, sync, sync.shard(X, bl), eps[s][lo:hi]) for s in range(3)]
         tot = sync.sum_scalar(float(rank + 1), "cpu")
+        # the same steps through the bucketed schedule (two all-reduces of ranges, started as the ranges appear)
+        rep2 = BucketedReplica(bl, B_GLOBAL, p0)
+        costs2 = [dp_train_step_bucketed(rep2, sync, oracle_buckets(), sync.shard(X, bl), eps[s][lo:hi]) for s in range(3)]
+        assert costs2 == costs and np.array_equal(rep2.model.get_params(), rep.model.get_params())
+        # the ncclUniqueId bootstrap: rank 0's bytes on every rank
+        got = sync.broadcast_bytes(bytes(range(128)) if rank == 0 else b"", 128)
+        assert got == bytes(range(128))
         np.savez(os.path.join(out_dir, "r%d.npz" % rank), costs=np.array(costs), params=rep.model.get_params(), tot=tot)
     finally:
         dist.destroy_process_group()

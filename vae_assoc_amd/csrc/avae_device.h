@@ -144,6 +144,7 @@ struct AdamArgs {
     int n_items;
     int base[kMaxAdamItems];           // first tile of every item (by value: no dependent scan through HBM)
     int mode;                // 0: Adam update; 1: refresh shadows from theta only
+    int book;                // 1: this launch books the step's cost (last_cost, cost history)
     float lr, beta1, beta2, eps;
     DevState* st;
     const float* cost_src;   // grad[cost slot]

@@ -3,6 +3,8 @@
 #include "avae_device.h"
 #include "../../include/avae.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -171,6 +173,23 @@ struct avae_handle {
     std::vector<WorkItem> items;            // training + eval tables (host mirror)
     std::vector<Launch> fwd, bwd;           // training launches: forward, dgrad chain
     std::vector<Launch> wgrad;              // all weight gradients (-> [all-reduce ->] k_adam)
+    // Data-parallel buckets: bucket 0 = the decoder side of every modality (output layer, decoder layers: their weight gradients
+    // can be taken as soon as bwd_dec1_latent has run), bucket 1 = the encoder side (heads, encoder layers: after the last dgrad).
+    // The all-reduce of bucket 0 runs beside the encoder's dgrad chain and bucket 1's weight gradients; Adam is applied per bucket.
+    int n_buckets = 1;                      // 1: models with a conv modality (their helper launches are not bucketed)
+    int bwd_split = 0;                      // h->bwd[0 .. bwd_split) belongs to bucket 0's part of the step, the rest to bucket 1's
+    std::vector<Launch> wgrad_b[2];
+    struct Range { size_t off, count; };    // floats inside the gradient buffer (the cost slot rides at the end of the last range of bucket 0)
+    std::vector<Range> ranges_b[2];
+    int adam_first_b[2] = {0, 0}, adam_count_b[2] = {0, 0}, adam_blocks_b[2] = {0, 0};   // items of the bucket-ordered copy of the Adam table
+    std::vector<AdamItem> adam_items_b;     // [bucket 0 items ..., bucket 1 items ...], tile bases per bucket
+    size_t off_adam_b = 0;
+    // library-owned collective (RCCL): one communicator per replica, its own stream, events between the two streams
+    void* comm = nullptr;
+    int comm_world = 1, comm_rank = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_grad[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
+    std::vector<hipGraphExec_t> g_dp[2];    // per staging set: captured segment of bucket b (forward + backward part + its weight gradients)
     Launch cost_only;                       // eval: K_COST alone, no step bump
     std::vector<AdamItem> adam_items;
     int adam_blocks = 0;
@@ -218,8 +237,9 @@ Act make_act(Bump& b, int width, bool ones, int rows, int KU, int es, int ld = 0
 Dense make_dense(Bump& b, size_t& pint, int in, int out, int KU, int es, bool head) {
     Dense d;
     d.in = in; d.out = out; d.head = head;
-    d.ld = (int)rup(out, KU);
-    d.ldw = spread_ld(d.ld, KU, es);
+    d.ld = (int)rup(out, 4);                       // theta / m / v / g rows: 16-byte aligned, no K padding (this layout is what the
+                                                   // gradient all-reduce puts on the wire: 5.89 MB for C2 against 5.87 MB of parameters)
+    d.ldw = spread_ld((int)rup(out, KU), KU, es);
     d.ldt = spread_ld((int)rup(in + 1, KU), KU, es);
     d.master = pint;
     pint += (size_t)(in + 1) * d.ld;
@@ -423,6 +443,7 @@ void plan_memory(avae_handle* h) {
     size_t n_adam = 0;
     for (int m = 0; m < h->M; ++m) n_adam += h->mods[m].conv ? 9 : 2 * (size_t)h->mods[m].L + 2;
     h->off_adam = b.take(n_adam * sizeof(AdamItem));
+    h->off_adam_b = b.take(n_adam * sizeof(AdamItem));
     h->off_inf = b.off;
     for (int m = 0; m < h->M; ++m) b.take(2 * ((size_t)h->mods[m].L + 1) * sizeof(WorkItem));
 #ifdef AVAE_STAMPS
@@ -1071,6 +1092,7 @@ void build_training_plan(avae_handle* h) {
         for (Mod& md : h->mods) if (!md.conv) h->items.push_back(bd.dgrad_latent(md));
         h->items.push_back(bd.cost(true));                       // every cost partial is final since fwd_out_loss: cost, step counter, lr_t
     });
+    h->bwd_split = (int)h->bwd.size();      // everything from here on belongs to the encoder side
     group("bwd_head", h->bwd, [&] {
         for (Mod& md : h->mods) {
             if (md.conv) h->items.push_back(bd.conv_dgrad(md.cenc[3], md.dH));
@@ -1117,23 +1139,51 @@ void build_training_plan(avae_handle* h) {
         // big problems: the narrow products (heads, first decoder layer) get launches of their own, or their presence
         // would hold the wide ones on 64x64 tiles (finish_launch picks one tile shape per launch)
         auto is_narrow = [](const WorkItem& w) { return w.N <= 64 || w.M <= 64; };
-        long wide128 = 0;
-        for (const WorkItem& w : wg) if (!is_narrow(w)) wide128 += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
-        std::vector<std::vector<WorkItem>> chunks;
-        auto chunk_up = [&](const std::vector<WorkItem>& v) {
-            for (size_t i0 = 0; i0 < v.size(); i0 += kMaxTnItems)
-                chunks.emplace_back(v.begin() + i0, v.begin() + std::min(v.size(), i0 + (size_t)kMaxTnItems));
+        auto wgrad_launches = [&](const std::vector<WorkItem>& set, std::vector<Launch>& dst, const std::string& prefix) {
+            long wide128 = 0;
+            for (const WorkItem& w : set) if (!is_narrow(w)) wide128 += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
+            std::vector<std::vector<WorkItem>> chunks;
+            auto chunk_up = [&](const std::vector<WorkItem>& v) {
+                for (size_t i0 = 0; i0 < v.size(); i0 += kMaxTnItems)
+                    chunks.emplace_back(v.begin() + i0, v.begin() + std::min(v.size(), i0 + (size_t)kMaxTnItems));
+            };
+            if (wide128 >= 192) {
+                std::vector<WorkItem> wide, narrow;
+                for (const WorkItem& w : set) (is_narrow(w) ? narrow : wide).push_back(w);
+                chunk_up(wide); chunk_up(narrow);
+            } else {
+                chunk_up(set);
+            }
+            for (size_t c = 0; c < chunks.size(); ++c) {
+                group(prefix + (chunks.size() > 1 ? std::to_string(c + 1) : std::string()), dst,
+                      [&] { for (const WorkItem& w : chunks[c]) h->items.push_back(w); });
+            }
         };
-        if (wide128 >= 192) {
-            std::vector<WorkItem> wide, narrow;
-            for (const WorkItem& w : wg) (is_narrow(w) ? narrow : wide).push_back(w);
-            chunk_up(wide); chunk_up(narrow);
+        wgrad_launches(wg, h->wgrad, "wgrad");
+        // the same weight gradients cut into the two data-parallel buckets (MLP-only models)
+        h->n_buckets = any_conv ? 1 : 2;
+        h->wgrad_b[0].clear(); h->wgrad_b[1].clear();
+        h->ranges_b[0].clear(); h->ranges_b[1].clear();
+        if (h->n_buckets == 2) {
+            std::vector<WorkItem> set[2];
+            for (Mod& md : h->mods) {
+                set[0].push_back(bd.wgrad(md.D.back(), md.outl, md.dO));
+                for (int k = md.L - 1; k >= 1; --k) set[0].push_back(bd.wgrad(md.D[k - 1], md.dec[k], md.dD[k]));
+                set[0].push_back(bd.wgrad(md.Z, md.dec[0], md.dD[0]));
+                set[1].push_back(bd.wgrad(md.E.back(), md.head, md.dH));
+                for (int k = md.L - 1; k >= 1; --k) set[1].push_back(bd.wgrad(md.E[k - 1], md.enc[k], md.dE[k]));
+                set[1].push_back(bd.wgrad(md.X0, md.enc[0], md.dE[0]));
+                // the master layout of a modality is [enc..., head | dec..., out]: one contiguous range per bucket and modality
+                const size_t enc_lo = md.enc[0].master, dec_lo = md.dec[0].master, dec_hi = md.outl.master + (size_t)(md.outl.in + 1) * md.outl.ld;
+                h->ranges_b[1].push_back({enc_lo, dec_lo - enc_lo});
+                h->ranges_b[0].push_back({dec_lo, dec_hi - dec_lo});
+            }
+            if (h->ranges_b[0].back().off + h->ranges_b[0].back().count != h->P_int) throw Err("internal error: the cost slot does not follow the last decoder range");
+            h->ranges_b[0].back().count += 1;                    // + the step's cost (final since bwd_dec1_latent)
+            wgrad_launches(set[0], h->wgrad_b[0], "wgrad_dec");
+            wgrad_launches(set[1], h->wgrad_b[1], "wgrad_enc");
         } else {
-            chunk_up(wg);
-        }
-        for (size_t c = 0; c < chunks.size(); ++c) {
-            group("wgrad" + (chunks.size() > 1 ? std::to_string(c + 1) : std::string()), h->wgrad,
-                  [&] { for (const WorkItem& w : chunks[c]) h->items.push_back(w); });
+            h->ranges_b[0].push_back({0, h->P_int + 1});
         }
         for (int i = 1; i <= 3; ++i) if (is_thin(i)) thin_launch("conv_dec" + std::to_string(i + 1) + "_wgrad_direct", h->wgrad, 2, i);
         {   // bias gradients of the adjoint-frame stages = column sums of their output gradient, first level
@@ -1257,6 +1307,27 @@ void build_training_plan(avae_handle* h) {
         add(md.outl);
     }
     h->adam_blocks = base;
+    // bucket-ordered copy: per modality the items are [enc x L, head, dec x L, out]
+    h->adam_items_b.clear();
+    for (int bk = 0; bk < 2; ++bk) {
+        h->adam_first_b[bk] = (int)h->adam_items_b.size();
+        int tb = 0;
+        size_t i = 0;
+        for (const Mod& md : h->mods) {
+            const size_t n_enc = md.conv ? md.cenc.size() : (size_t)md.L + 1, n_all = md.conv ? md.cenc.size() + md.cdec.size() : 2 * (size_t)md.L + 2;
+            for (size_t k = 0; k < n_all; ++k) {
+                const int which = h->n_buckets == 1 ? 0 : (k < n_enc ? 1 : 0);
+                if (which == bk) {
+                    AdamItem a = h->adam_items[i + k];
+                    a.tile_base = tb; tb += a.tiles_r * a.tiles_c;
+                    h->adam_items_b.push_back(a);
+                }
+            }
+            i += n_all;
+        }
+        h->adam_count_b[bk] = (int)h->adam_items_b.size() - h->adam_first_b[bk];
+        h->adam_blocks_b[bk] = tb;
+    }
 }
 
 void build_inference(avae_handle* h, int m, bool enc, int rows) {
@@ -1372,18 +1443,28 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
     }
 }
 
-void run_adam(avae_handle* h, int mode, hipStream_t s) {
+void run_adam(avae_handle* h, int mode, hipStream_t s, int bucket = -1) {
     AdamArgs a;
-    a.items = h->at<AdamItem>(h->off_adam);
-    a.n_items = (int)h->adam_items.size();
-    if (a.n_items > kMaxAdamItems) throw Err("internal error: too many Adam items");
-    for (int i = 0; i < a.n_items; ++i) a.base[i] = h->adam_items[i].tile_base;
+    int blocks = h->adam_blocks;
+    if (bucket < 0) {
+        a.items = h->at<AdamItem>(h->off_adam);
+        a.n_items = (int)h->adam_items.size();
+        if (a.n_items > kMaxAdamItems) throw Err("internal error: too many Adam items");
+        for (int i = 0; i < a.n_items; ++i) a.base[i] = h->adam_items[i].tile_base;
+    } else {
+        a.items = h->at<AdamItem>(h->off_adam_b) + h->adam_first_b[bucket];
+        a.n_items = h->adam_count_b[bucket];
+        for (int i = 0; i < a.n_items; ++i) a.base[i] = h->adam_items_b[h->adam_first_b[bucket] + i].tile_base;
+        blocks = h->adam_blocks_b[bucket];
+        if (blocks == 0) return;
+    }
+    a.book = (bucket <= 0) ? 1 : 0;            // the bucket that carries the cost slot books the step's cost
     a.mode = mode;
     a.lr = h->cfg.learning_rate; a.beta1 = h->cfg.beta1; a.beta2 = h->cfg.beta2; a.eps = h->cfg.adam_eps;
     a.st = h->state();
     a.cost_src = h->grad() + h->P_int;
-    Timed t(h, s, mode == 0 ? "adam" : "shadow_refresh");
-    launch_adam(h->cfg.compute_dtype, a, h->adam_blocks, s);
+    Timed t(h, s, mode == 0 ? (bucket < 0 ? "adam" : bucket == 0 ? "adam_dec" : "adam_enc") : "shadow_refresh");
+    launch_adam(h->cfg.compute_dtype, a, blocks, s);
     LAUNCH_OK(mode == 0 ? "adam" : "shadow_refresh");
 }
 
@@ -1530,6 +1611,7 @@ void init_device(avae_handle* h) {
     }
     build_training_plan(h);
     HIP_OK(hipMemcpyAsync(h->at<void>(h->off_adam), h->adam_items.data(), h->adam_items.size() * sizeof(AdamItem), hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(h->at<void>(h->off_adam_b), h->adam_items_b.data(), h->adam_items_b.size() * sizeof(AdamItem), hipMemcpyHostToDevice, s));
     size_t off = h->off_inf;
     h->inf_enc.assign(h->M, avae_handle::Inf());
     h->inf_dec.assign(h->M, avae_handle::Inf());
@@ -1615,6 +1697,123 @@ void host_to_master(avae_handle* h, size_t off, const std::vector<float>& host) 
     HIP_OK(hipMemcpy(h->at<void>(off), host.data(), h->P_int * 4, hipMemcpyHostToDevice));
 }
 
+// ----------------------------------------------------------------------------- RCCL (loaded at run time)
+// The process usually has an RCCL already (PyTorch-ROCm bundles one): that copy is used when present, the system's otherwise.
+// Only the five entry points the gradient all-reduce needs are bound; no RCCL header is needed at build time.
+struct Rccl {
+    struct Id { char b[128]; };                 // ncclUniqueId (passed by value)
+    typedef int (*get_id_t)(void*);
+    typedef int (*init_rank_t)(void**, int, Id, int);
+    typedef int (*all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef int (*destroy_t)(void*);
+    typedef const char* (*err_t)(int);
+    typedef int (*group_t)();
+    void* lib = nullptr;
+    get_id_t get_id = nullptr; init_rank_t init_rank = nullptr; all_reduce_t all_reduce = nullptr; destroy_t destroy = nullptr;
+    err_t err_str = nullptr; group_t group_start = nullptr, group_end = nullptr;
+    static Rccl& get() {
+        static Rccl r;
+        static std::once_flag once;
+        std::call_once(once, [] {
+            const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+            for (const char* n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;       // the copy already in the process
+            for (const char* n : names) { if (r.lib) break; r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
+            if (!r.lib) return;
+            r.get_id = (get_id_t)dlsym(r.lib, "ncclGetUniqueId"); r.init_rank = (init_rank_t)dlsym(r.lib, "ncclCommInitRank");
+            r.all_reduce = (all_reduce_t)dlsym(r.lib, "ncclAllReduce"); r.destroy = (destroy_t)dlsym(r.lib, "ncclCommDestroy");
+            r.err_str = (err_t)dlsym(r.lib, "ncclGetErrorString");
+            r.group_start = (group_t)dlsym(r.lib, "ncclGroupStart"); r.group_end = (group_t)dlsym(r.lib, "ncclGroupEnd");
+        });
+        if (!r.lib || !r.get_id || !r.init_rank || !r.all_reduce || !r.destroy || !r.group_start || !r.group_end)
+            throw Err("RCCL is not available (librccl.so could not be loaded): the library-owned gradient all-reduce needs it");
+        return r;
+    }
+};
+#define NCCL_OK(expr)                                                                            \
+    do {                                                                                         \
+        int r_ = (expr);                                                                         \
+        if (r_ != 0) throw Err(std::string(#expr) + ": " + (Rccl::get().err_str ? Rccl::get().err_str(r_) : "RCCL error") + " (" + std::to_string(r_) + ")"); \
+    } while (0)
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;        // rccl.h: ncclFloat32, ncclSum
+
+void comm_init(avae_handle* h) {
+    Rccl& R = Rccl::get();
+    if (h->cfg.world_size < 1 || h->cfg.rank < 0 || h->cfg.rank >= h->cfg.world_size) throw Err("use_comm: world_size / rank out of range");
+    Rccl::Id id;
+    std::memcpy(id.b, h->cfg.nccl_id, 128);
+    NCCL_OK(R.init_rank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
+    h->comm_world = h->cfg.world_size; h->comm_rank = h->cfg.rank;
+    HIP_OK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        HIP_OK(hipEventCreateWithFlags(&h->ev_grad[b], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_red[b], hipEventDisableTiming));
+    }
+}
+
+// ranges of bucket b, from the memory plan alone (so that avae_dp_plan needs no device)
+void dp_ranges(const avae_handle* h, int* n_buckets, std::vector<avae_handle::Range> (&out)[2]) {
+    bool any_conv = false;
+    for (const Mod& md : h->mods) any_conv = any_conv || md.conv;
+    out[0].clear(); out[1].clear();
+    if (any_conv) { *n_buckets = 1; out[0].push_back({0, h->P_int + 1}); return; }
+    *n_buckets = 2;
+    for (const Mod& md : h->mods) {
+        const size_t enc_lo = md.enc[0].master, dec_lo = md.dec[0].master, dec_hi = md.outl.master + (size_t)(md.outl.in + 1) * md.outl.ld;
+        out[1].push_back({enc_lo, dec_lo - enc_lo});
+        out[0].push_back({dec_lo, dec_hi - dec_lo});
+    }
+    out[0].back().count += 1;      // + the cost slot (element P_int follows the last modality's output layer)
+}
+
+// forward + the backward part of bucket b + its weight gradients, on staging set j
+void dp_segment(avae_handle* h, int j, int bucket, hipStream_t s) {
+    if (bucket < 0 || bucket >= h->n_buckets) throw Err("data-parallel bucket out of range");
+    if (j < 0 || j >= kMultiSteps) throw Err("staging set out of range");
+    auto body = [&](hipStream_t cs) {
+        auto run = [&](const std::vector<Launch>& ls, size_t lo, size_t hi) {
+            std::vector<Launch> moved;
+            for (size_t i = lo; i < hi && i < ls.size(); ++i) moved.push_back(relocated(h, ls[i], j));
+            run_launches(h, moved, cs);
+        };
+        if (h->n_buckets == 1) { run(h->fwd, 0, h->fwd.size()); run(h->bwd, 0, h->bwd.size()); run(h->wgrad, 0, h->wgrad.size()); return; }
+        if (bucket == 0) { run(h->fwd, 0, h->fwd.size()); run(h->bwd, 0, (size_t)h->bwd_split); run(h->wgrad_b[0], 0, h->wgrad_b[0].size()); }
+        else { run(h->bwd, (size_t)h->bwd_split, h->bwd.size()); run(h->wgrad_b[1], 0, h->wgrad_b[1].size()); }
+    };
+    if (h->cfg.use_graph && !h->timing) {
+        if (h->g_dp[bucket].empty()) h->g_dp[bucket].assign(kMultiSteps, nullptr);
+        if (!h->g_dp[bucket][j]) h->g_dp[bucket][j] = capture(h, body);
+        HIP_OK(hipGraphLaunch(h->g_dp[bucket][j], s));
+    } else {
+        body(s);
+    }
+}
+
+// one step of the library-owned data-parallel pipeline on staging set j (main stream s, collective on the comm stream)
+void dp_step(avae_handle* h, int j, hipStream_t s) {
+    Rccl& R = Rccl::get();
+    float* g = h->grad();
+    for (int b = 0; b < h->n_buckets; ++b) {
+        dp_segment(h, j, b, s);
+        HIP_OK(hipEventRecord(h->ev_grad[b], s));
+        HIP_OK(hipStreamWaitEvent(h->comm_stream, h->ev_grad[b], 0));
+        {
+            Timed t(h, h->comm_stream, b == 0 ? "allreduce_dec" : "allreduce_enc");
+            t_launch_events = LaunchEvents{nullptr, nullptr};      // (not a kernel launch of ours: bracket it with plain records instead)
+            if (t.on) (void)hipEventRecord(t.a, h->comm_stream);
+            NCCL_OK(R.group_start());
+            for (const avae_handle::Range& r : h->ranges_b[b])
+                NCCL_OK(R.all_reduce(g + r.off, g + r.off, r.count, kNcclFloat32, kNcclSum, h->comm, h->comm_stream));
+            NCCL_OK(R.group_end());
+            if (t.on) (void)hipEventRecord(t.b, h->comm_stream);
+        }
+        HIP_OK(hipEventRecord(h->ev_red[b], h->comm_stream));
+    }
+    for (int b = 0; b < h->n_buckets; ++b) {
+        HIP_OK(hipStreamWaitEvent(s, h->ev_red[b], 0));
+        run_adam(h, 0, s, h->n_buckets == 1 ? -1 : b);
+    }
+}
+
 }  // namespace
 
 // ============================================================================= C ABI
@@ -1662,11 +1861,18 @@ int avae_create(const avae_config* cfg, avae_handle** out) {
         }
         HIP_OK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
         init_device(h);
+        if (h->cfg.use_comm) comm_init(h);
         *out = h;
         return 0;
     } catch (const std::exception& e) {
         g_create_error = e.what();
-        if (h) { if (h->own_ws && h->ws) (void)hipFree(h->ws); if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream); delete h; }
+        if (h) {
+            if (h->comm) { try { (void)Rccl::get().destroy(h->comm); } catch (...) {} }
+            if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+            if (h->own_ws && h->ws) (void)hipFree(h->ws);
+            if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+            delete h;
+        }
         return 2;
     }
 }
@@ -1679,6 +1885,10 @@ void avae_destroy(avae_handle* h) {
     (void)hipDeviceSynchronize();
     for (hipGraphExec_t g : {h->g_full, h->g_multi[0], h->g_multi[1], h->g_bwd, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
     for (hipGraphExec_t g : h->g_bwd_set) if (g) (void)hipGraphExecDestroy(g);
+    for (int b = 0; b < 2; ++b) for (hipGraphExec_t g : h->g_dp[b]) if (g) (void)hipGraphExecDestroy(g);
+    if (h->comm) { try { (void)Rccl::get().destroy(h->comm); } catch (...) {} }
+    for (int b = 0; b < 2; ++b) { if (h->ev_grad[b]) (void)hipEventDestroy(h->ev_grad[b]); if (h->ev_red[b]) (void)hipEventDestroy(h->ev_red[b]); }
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     for (hipGraph_t g : {h->g_full_graph, h->g_multi_graph[0], h->g_multi_graph[1]}) if (g) (void)hipGraphDestroy(g);
     for (TimingRec& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -1785,6 +1995,12 @@ int avae_step_backward_staged(avae_handle* h, int32_t j, void* stream) {
 
 // one single-replica step
 void train_one(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, hipStream_t s) {
+    if (h->comm) {                      // library-owned collective: stage, then the bucketed pipeline
+        const PrepArgs a = make_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, 1);
+        { Timed t(h, s, "prep"); launch_prep(h->cfg.compute_dtype, a, s); LAUNCH_OK("prep"); }
+        dp_step(h, 0, s);
+        return;
+    }
     if (h->g_full && !h->timing) {      // the whole step, staging kernel included, is one graph replay
         patch_prep(h, h->g_full, h->g_full_prep, x_dev, x_ld, eps_dev);
         HIP_OK(hipGraphLaunch(h->g_full, s));
@@ -1823,6 +2039,17 @@ int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev,
             return eps_dev ? eps_dev + (size_t)i * h->B * h->nz : nullptr;
         };
         int i = 0;
+        if (h->comm) {                  // data parallel: batches staged kMultiSteps at a time, then backward -> all-reduce -> Adam per bucket and step
+            for (; i < n_steps; i += kMultiSteps) {
+                const int n = std::min(kMultiSteps, n_steps - i);
+                const float* e = batch(i);
+                const PrepArgs a = make_prep_batch(h, x.data(), x_ld, e, h->B, 0x7261696eull, n);
+                { Timed t(h, s, "prep"); launch_prep(h->cfg.compute_dtype, a, s); LAUNCH_OK("prep"); }
+                for (int j = 0; j < n; ++j) dp_step(h, j, s);
+            }
+            fetch_cost(h, cost_host, true, s);
+            return;
+        }
         for (int gi = 0; gi < 2 && !h->timing; ++gi)
             for (; h->g_multi[gi] && i + kMultiSizes[gi] <= n_steps; i += kMultiSizes[gi]) {
                 const float* e = batch(i);
@@ -1842,6 +2069,47 @@ int avae_grad_buffer(avae_handle* h, float** dev_ptr, size_t* n_floats) {
     *dev_ptr = h->grad();
     *n_floats = h->P_int + 1;     // gradient (internal padded layout) + the cost slot
     return 0;
+}
+
+int avae_dp_plan(const avae_config* cfg, int32_t* n_buckets, int32_t* n_ranges, int64_t* offs, int64_t* counts) {
+    try {
+        if (!cfg || !n_buckets || !n_ranges || !offs || !counts) throw Err("null argument");
+        check_config(*cfg);
+        avae_handle tmp;
+        tmp.cfg = *cfg;
+        plan_memory(&tmp);
+        std::vector<avae_handle::Range> r[2];
+        int nb = 0;
+        dp_ranges(&tmp, &nb, r);
+        *n_buckets = nb;
+        int k = 0;
+        for (int b = 0; b < 2; ++b) {
+            n_ranges[b] = (int32_t)r[b].size();
+            for (const avae_handle::Range& x : r[b]) { offs[k] = (int64_t)x.off; counts[k] = (int64_t)x.count; ++k; }
+        }
+        return 0;
+    } catch (const std::exception& e) { g_create_error = e.what(); return 2; }
+}
+
+int avae_dp_backward(avae_handle* h, int32_t j, int32_t bucket, void* stream) {
+    return guarded(h, [&] { dp_segment(h, j, bucket, reinterpret_cast<hipStream_t>(stream)); });
+}
+
+int avae_dp_apply(avae_handle* h, int32_t bucket, float* cost_host, void* stream) {
+    return guarded(h, [&] {
+        if (bucket < 0 || bucket >= h->n_buckets) throw Err("data-parallel bucket out of range");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        run_adam(h, 0, s, h->n_buckets == 1 ? -1 : bucket);
+        fetch_cost(h, cost_host, true, s);
+    });
+}
+
+int avae_comm_unique_id(void* id128) {
+    try {
+        if (!id128) throw Err("null argument");
+        NCCL_OK(Rccl::get().get_id(id128));
+        return 0;
+    } catch (const std::exception& e) { g_create_error = e.what(); return 2; }
 }
 
 int avae_cost_history(avae_handle* h, int32_t n, float* host_dst, int64_t* last_step) {

@@ -1249,7 +1249,7 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
     const int tr = t / w.tiles_c, tc = t - tr * w.tiles_c;
     const int r0 = tr * TR, c0 = tc * 64;
 
-    if (a.mode == 0 && tid == 0 && bid == 0) {              // step already counts this update (bumped by K_COST)
+    if (a.mode == 0 && a.book && tid == 0 && bid == 0) {    // step already counts this update (bumped by K_COST)
         const float c = *a.cost_src;
         a.st->last_cost = c;
         a.st->cost_hist[(a.st->step - 1) % kCostHist] = c;

@@ -32,6 +32,31 @@ class GradSync(object):
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
 
+    @property
+    def backend(self):
+        return dist.get_backend(self.group)
+
+    def broadcast_bytes(self, data, n, src=0):
+        """rank `src`'s n bytes on every rank (bootstrap of the library's RCCL communicator: the ncclUniqueId)"""
+        t = torch.zeros(n, dtype=torch.uint8)
+        if self.rank == src:
+            t = torch.tensor(list(bytes(data)), dtype=torch.uint8)
+        if self.world_size > 1:
+            if self.backend == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=src, group=self.group)
+        return bytes(t.cpu().tolist())
+
+    def all_reduce_ranges_(self, flat, ranges, async_op=False):
+        """In-place SUM all-reduce of the (offset, count) float ranges of one bucket of the flat gradient buffer."""
+        works = []
+        if self.world_size > 1:
+            for off, cnt in ranges:
+                w = dist.all_reduce(flat[off:off + cnt], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                if async_op:
+                    works.append(w)
+        return works
+
     def all_reduce_(self, flat):
         """In-place SUM all-reduce of the flat gradient(+cost) buffer."""
         if self.world_size > 1:
@@ -66,3 +91,23 @@ def dp_train_step(replica, sync, X_local, eps_local=None):
     replica._backward(X_local, eps_local)
     sync.all_reduce_(replica._grad_tensor())
     return replica._apply()
+
+
+def dp_train_step_bucketed(replica, sync, buckets, X_local, eps_local=None):
+    """The same step cut into gradient buckets (a list of range lists, in the order their gradients become available):
+    backward part b -> all-reduce of bucket b's ranges, started as soon as they exist and left running beside backward part
+    b+1 -> Adam per bucket once its ranges have arrived.  The replica provides ``_stage(X, eps)``, ``_backward_bucket(b)``,
+    ``_grad_tensor()`` and ``_apply_bucket(b, want_cost)``; the library-owned RCCL pipeline (avae_host.hip::dp_step) is this
+    schedule on two HIP streams."""
+    replica._stage(X_local, eps_local)
+    g = replica._grad_tensor()
+    pending = []
+    for b, ranges in enumerate(buckets):
+        replica._backward_bucket(b)
+        pending.append(sync.all_reduce_ranges_(g, ranges, async_op=True))
+    cost = None
+    for b in range(len(buckets)):
+        for w in pending[b]:
+            w.wait()
+        cost = replica._apply_bucket(b, b == len(buckets) - 1)
+    return cost

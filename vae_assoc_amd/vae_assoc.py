@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .parallel import GradSync
+from .parallel import GradSync, dp_train_step_bucketed
 
 _ARCH_KEYS = ("scope", "hidden_conv", "n_hidden_recog_1", "n_hidden_recog_2",
               "n_hidden_gener_1", "n_hidden_gener_2", "n_input", "n_z")
@@ -93,13 +93,17 @@ class AssocVariationalAutoEncoder(object):
       device         torch device / ordinal (default: current CUDA(HIP) device)
       seed           seeds the NumPy weight draw and the in-kernel eps generator
       use_graph      replay the step as a captured hipGraph
-      data_parallel  True -> one replica per torch.distributed rank, sample-sharded batch,
-                     one SUM all-reduce of the flat gradient per step (RCCL over xGMI)
+      data_parallel  True -> one replica per torch.distributed rank, sample-sharded batch, the gradient SUM-all-reduced per
+                     step in two buckets (decoder side first, overlapping the encoder's backward pass), Adam per bucket
+      comm           who owns that collective: 'library' = libavae's own RCCL communicator (ncclAllReduce on the library's
+                     streams; torch.distributed only hands the ncclUniqueId round), 'torch' = torch.distributed all_reduce over
+                     the same buckets; None = 'library' when the process group's backend is nccl, else 'torch' (gloo tests).
+                     comm='library' without data_parallel builds a one-rank communicator (tests)
     """
 
     def __init__(self, network_architectures, binary=True, transfer_fct="softplus", weights=1.0,
                  assoc_lambda=1.0, learning_rate=0.001, batch_size=100, *, compute_dtype="bf16",
-                 device=None, seed=0, use_graph=True, data_parallel=False, process_group=None):
+                 device=None, seed=0, use_graph=True, data_parallel=False, process_group=None, comm=None):
         self.network_architectures = network_architectures
         self.assoc_lambda = assoc_lambda
         n_mod = len(network_architectures)
@@ -138,6 +142,11 @@ class AssocVariationalAutoEncoder(object):
         self._sync = GradSync(process_group) if data_parallel else None
         world = self._sync.world_size if self._sync else 1
         rank = self._sync.rank if self._sync else 0
+        if comm not in (None, "library", "torch"):
+            raise ValueError("comm must be None, 'library' or 'torch'")
+        if comm is None:
+            comm = "library" if (self._sync is not None and self._sync.backend == "nccl") else "torch"
+        self._comm_lib = comm == "library"
 
         cfg = _capi.Config()
         cfg.abi_version = _capi.AVAE_ABI_VERSION
@@ -174,6 +183,23 @@ class AssocVariationalAutoEncoder(object):
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
 
         L = _capi.lib()
+        if self._comm_lib:
+            # bootstrap only: rank 0 draws the ncclUniqueId, torch.distributed hands it round; the communicator itself is the library's
+            idb = (C.c_uint8 * 128)()
+            if rank == 0:
+                _capi.check(None, L.avae_comm_unique_id(idb), "avae_comm_unique_id")
+            raw = self._sync.broadcast_bytes(bytes(idb), 128) if self._sync is not None else bytes(idb)
+            cfg.use_comm, cfg.world_size, cfg.rank = 1, world, rank
+            for i in range(128):
+                cfg.nccl_id[i] = raw[i]
+        # data-parallel buckets (host-only query): [[(offset, count), ...] per bucket]
+        nb, nr = C.c_int32(0), (C.c_int32 * 2)()
+        offs, cnts = (C.c_int64 * (2 * _capi.AVAE_MAX_MODALITIES))(), (C.c_int64 * (2 * _capi.AVAE_MAX_MODALITIES))()
+        _capi.check(None, L.avae_dp_plan(C.byref(cfg), C.byref(nb), nr, offs, cnts), "avae_dp_plan")
+        self._buckets, k = [], 0
+        for b in range(nb.value):
+            self._buckets.append([(int(offs[k + i]), int(cnts[k + i])) for i in range(nr[b])])
+            k += nr[b]
         nbytes = C.c_size_t(0)
         _capi.check(None, L.avae_workspace_bytes(C.byref(cfg), C.byref(nbytes)), "avae_workspace_bytes")
         # PyTorch is the device allocator: one uint8 tensor holds the whole replica state
@@ -306,6 +332,21 @@ class AssocVariationalAutoEncoder(object):
     def _grad_tensor(self):
         return self._grad_view
 
+    # bucketed seam (parallel.dp_train_step_bucketed): stage -> per bucket backward / all-reduce -> per bucket Adam
+    def _stage(self, X, eps=None, n_steps=1):
+        ts, ptrs, lds, e = self._batch_args(X, eps, n_steps)
+        _capi.check(self._h, self._L.avae_stage_batches(self._h, n_steps, ptrs, lds, e.data_ptr() if e is not None else None,
+                                                        self._stream()), "avae_stage_batches")
+        self._staged_j = 0
+
+    def _backward_bucket(self, b):
+        _capi.check(self._h, self._L.avae_dp_backward(self._h, self._staged_j, b, self._stream()), "avae_dp_backward")
+
+    def _apply_bucket(self, b, want_cost=True):
+        cost = C.c_float(0.0)
+        _capi.check(self._h, self._L.avae_dp_apply(self._h, b, C.byref(cost) if want_cost else None, self._stream()), "avae_dp_apply")
+        return cost.value if want_cost else None
+
     def _apply(self, want_cost=True):
         cost = C.c_float(0.0)
         _capi.check(self._h, self._L.avae_step_apply(self._h, C.byref(cost) if want_cost else None, self._stream()),
@@ -317,11 +358,11 @@ class AssocVariationalAutoEncoder(object):
         """Train model based on mini-batch of input data.  Return cost of mini-batch.
         (reference vae_assoc.py:378-386).  ``return_cost=False`` skips the host synchronise;
         the cost stays retrievable through ``cost_history``."""
-        if self._sync is not None and self._sync.world_size > 1:
-            self._backward(X, eps)
-            self._sync.all_reduce_(self._grad_view)
-            return self._apply(return_cost)
-        ts, ptrs, lds, e = self._batch_args(X, eps)
+        if self._sync is not None and self._sync.world_size > 1 and not self._comm_lib:
+            # host-owned collective (torch.distributed) over the library's buckets
+            cost = dp_train_step_bucketed(self, self._sync, self._buckets, X, eps)
+            return cost if return_cost else None
+        ts, ptrs, lds, e = self._batch_args(X, eps)      # (library-owned collective: avae_train_step runs the bucketed pipeline itself)
         cost = C.c_float(0.0)
         _capi.check(self._h, self._L.avae_train_step(self._h, ptrs, lds, e.data_ptr() if e is not None else None,
                                                      C.byref(cost) if return_cost else None, self._stream()),
@@ -334,8 +375,8 @@ class AssocVariationalAutoEncoder(object):
         loop does with ``DataSet.next_batch``'s consecutive slices (vae_assoc.py:541-550).  Returns the
         last step's cost; every step's cost is in ``cost_history``."""
         n_steps = int(n_steps)
-        if self._sync is not None and self._sync.world_size > 1:
-            # the all-reduce sits between backward and Adam of every step; the batches are staged 16 at a time
+        if self._sync is not None and self._sync.world_size > 1 and not self._comm_lib:
+            # host-owned collective: the batches are staged 16 at a time, every step runs the bucketed schedule
             ts, ptrs, lds, e = self._batch_args(X, eps, n_steps)
             B, cost, st = self.batch_size, None, self._stream()
             for i0 in range(0, n_steps, 16):
@@ -344,9 +385,15 @@ class AssocVariationalAutoEncoder(object):
                 e_i = (e.data_ptr() + i0 * B * self.n_z * 4) if e is not None else None
                 _capi.check(self._h, self._L.avae_stage_batches(self._h, n, p_i, lds, e_i, st), "avae_stage_batches")
                 for j in range(n):
-                    _capi.check(self._h, self._L.avae_step_backward_staged(self._h, j, st), "avae_step_backward_staged")
-                    self._sync.all_reduce_(self._grad_view)
-                    cost = self._apply(return_cost and i0 + j == n_steps - 1)
+                    self._staged_j = j
+                    pending = []
+                    for b, ranges in enumerate(self._buckets):
+                        self._backward_bucket(b)
+                        pending.append(self._sync.all_reduce_ranges_(self._grad_view, ranges, async_op=True))
+                    for b in range(len(self._buckets)):
+                        for w in pending[b]:
+                            w.wait()
+                        cost = self._apply_bucket(b, return_cost and i0 + j == n_steps - 1 and b == len(self._buckets) - 1)
             return cost
         ts, ptrs, lds, e = self._batch_args(X, eps, n_steps)
         cost = C.c_float(0.0)
