@@ -219,7 +219,8 @@ def measure(name, args, world, rank, local_rank, steps, warmup, repeats, kernel_
     dtype = dtype or cfg_dtype
     es = 2 if dtype == "bf16" else 4
     model = AssocVariationalAutoEncoder(archs, transfer_fct="relu", batch_size=B, compute_dtype=dtype, device=local_rank,
-                                        seed=0, use_graph=not args.no_graph, data_parallel=world > 1, **hyper_for(archs))
+                                        seed=0, use_graph=not args.no_graph, data_parallel=world > 1,
+                                        comm="library" if (args.force_comm and world == 1) else None, **hyper_for(archs))
     # resident synthetic data: 16 batches per rank (rank r owns global rows [r*B, (r+1)*B) of each global batch)
     nb = 16
     rng = np.random.default_rng(20260104 + rank)
@@ -362,6 +363,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the short C4 / c2conv / C5 / C1 runs that ride behind the headline")
     ap.add_argument("--kernel-steps", type=int, default=200, help="steps of the per-kernel hipEvent pass")
     ap.add_argument("--single-step", action="store_true", help="submit every step on its own (avae_train_step) instead of in runs")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="one GPU: run the step through the library's data-parallel pipeline (one-rank RCCL communicator, two buckets, "
+                         "comm stream) to see what the pipeline itself costs; not the headline")
     ap.add_argument("--host-input", action="store_true",
                     help="also time the step fed from pinned host batches (PCIe-inclusive rate; reported beside `value`, never as it)")
     args = ap.parse_args()
@@ -416,6 +420,8 @@ def main():
             "dtype": res["dtype"], "data": "synthetic",
             "config": {"workload": res["label"], "global_batch": B * world, "per_gpu_batch": B, "n_params": pr["n_params"] or res["n_params"],
                        "parallelism": "dp%d" % world, "graph": not args.no_graph,
+                       "collective": ("library-owned RCCL communicator, 2 buckets, all-reduce of the decoder bucket beside the encoder's backward pass"
+                                      if (world > 1 or args.force_comm) else "none (one replica)"),
                        "submission": "per step" if args.single_step else "runs of <=16 consecutive resident batches"},
             "timing": {"repeats": args.repeats, "statistic": "median of the repeats, each EXACTLY --steps steps between barrier + synchronise",
                        "ms_per_step_all": [round(d / steps * 1e3, 5) for d in res["dts"]]},

@@ -4,6 +4,7 @@
 #include "../../include/avae.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -190,6 +191,11 @@ struct avae_handle {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_grad[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
     std::vector<hipGraphExec_t> g_dp[2];    // per staging set: captured segment of bucket b (forward + backward part + its weight gradients)
+    // whole runs of data-parallel steps as ONE graph (staging + per step: segments, all-reduces on the comm stream, Adam per bucket):
+    hipGraphExec_t g_dpm[2] = {nullptr, nullptr};
+    hipGraph_t g_dpm_graph[2] = {nullptr, nullptr};
+    hipGraphNode_t g_dpm_prep[2] = {nullptr, nullptr};
+    bool dp_graph_failed = false;           // RCCL refused stream capture on this stack: host-stepped pipeline instead
     Launch cost_only;                       // eval: K_COST alone, no step bump
     std::vector<AdamItem> adam_items;
     int adam_blocks = 0;
@@ -237,8 +243,9 @@ Act make_act(Bump& b, int width, bool ones, int rows, int KU, int es, int ld = 0
 Dense make_dense(Bump& b, size_t& pint, int in, int out, int KU, int es, bool head) {
     Dense d;
     d.in = in; d.out = out; d.head = head;
-    d.ld = (int)rup(out, 4);                       // theta / m / v / g rows: 16-byte aligned, no K padding (this layout is what the
-                                                   // gradient all-reduce puts on the wire: 5.89 MB for C2 against 5.87 MB of parameters)
+    d.ld = (int)rup(out, 32);                      // theta / m / v / g rows: whole 128-byte lines (k_adam streams them: rows cut at 16 bytes
+                                                   // cost it 9.0 -> 11.75 us on C2), not padded to the K unit.  This layout is what the gradient
+                                                   // all-reduce puts on the wire: 6.13 MB for C2's 5.87 MB of parameters (6.6 MB padded to K)
     d.ldw = spread_ld((int)rup(out, KU), KU, es);
     d.ldt = spread_ld((int)rup(in + 1, KU), KU, es);
     d.master = pint;
@@ -1741,7 +1748,16 @@ void comm_init(avae_handle* h) {
     if (h->cfg.world_size < 1 || h->cfg.rank < 0 || h->cfg.rank >= h->cfg.world_size) throw Err("use_comm: world_size / rank out of range");
     Rccl::Id id;
     std::memcpy(id.b, h->cfg.nccl_id, 128);
-    NCCL_OK(R.init_rank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
+    {   // RCCL prints a version banner on stdout when its first communicator comes up; the host's stdout may be a protocol
+        // (bench.py: one JSON line): send it to stderr
+        std::fflush(stdout);
+        const int saved = dup(1);
+        if (saved >= 0) (void)dup2(2, 1);
+        const int rc = R.init_rank(&h->comm, h->cfg.world_size, id, h->cfg.rank);
+        std::fflush(stdout);
+        if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
+        NCCL_OK(rc);
+    }
     h->comm_world = h->cfg.world_size; h->comm_rank = h->cfg.rank;
     HIP_OK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b) {
@@ -1766,7 +1782,7 @@ void dp_ranges(const avae_handle* h, int* n_buckets, std::vector<avae_handle::Ra
 }
 
 // forward + the backward part of bucket b + its weight gradients, on staging set j
-void dp_segment(avae_handle* h, int j, int bucket, hipStream_t s) {
+void dp_segment(avae_handle* h, int j, int bucket, hipStream_t s, bool direct = false) {
     if (bucket < 0 || bucket >= h->n_buckets) throw Err("data-parallel bucket out of range");
     if (j < 0 || j >= kMultiSteps) throw Err("staging set out of range");
     auto body = [&](hipStream_t cs) {
@@ -1779,7 +1795,7 @@ void dp_segment(avae_handle* h, int j, int bucket, hipStream_t s) {
         if (bucket == 0) { run(h->fwd, 0, h->fwd.size()); run(h->bwd, 0, (size_t)h->bwd_split); run(h->wgrad_b[0], 0, h->wgrad_b[0].size()); }
         else { run(h->bwd, (size_t)h->bwd_split, h->bwd.size()); run(h->wgrad_b[1], 0, h->wgrad_b[1].size()); }
     };
-    if (h->cfg.use_graph && !h->timing) {
+    if (h->cfg.use_graph && !h->timing && !direct) {
         if (h->g_dp[bucket].empty()) h->g_dp[bucket].assign(kMultiSteps, nullptr);
         if (!h->g_dp[bucket][j]) h->g_dp[bucket][j] = capture(h, body);
         HIP_OK(hipGraphLaunch(h->g_dp[bucket][j], s));
@@ -1789,11 +1805,11 @@ void dp_segment(avae_handle* h, int j, int bucket, hipStream_t s) {
 }
 
 // one step of the library-owned data-parallel pipeline on staging set j (main stream s, collective on the comm stream)
-void dp_step(avae_handle* h, int j, hipStream_t s) {
+void dp_step(avae_handle* h, int j, hipStream_t s, bool direct = false) {
     Rccl& R = Rccl::get();
     float* g = h->grad();
     for (int b = 0; b < h->n_buckets; ++b) {
-        dp_segment(h, j, b, s);
+        dp_segment(h, j, b, s, direct);
         HIP_OK(hipEventRecord(h->ev_grad[b], s));
         HIP_OK(hipStreamWaitEvent(h->comm_stream, h->ev_grad[b], 0));
         {
@@ -1886,6 +1902,7 @@ void avae_destroy(avae_handle* h) {
     for (hipGraphExec_t g : {h->g_full, h->g_multi[0], h->g_multi[1], h->g_bwd, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
     for (hipGraphExec_t g : h->g_bwd_set) if (g) (void)hipGraphExecDestroy(g);
     for (int b = 0; b < 2; ++b) for (hipGraphExec_t g : h->g_dp[b]) if (g) (void)hipGraphExecDestroy(g);
+    for (int gi = 0; gi < 2; ++gi) { if (h->g_dpm[gi]) (void)hipGraphExecDestroy(h->g_dpm[gi]); if (h->g_dpm_graph[gi]) (void)hipGraphDestroy(h->g_dpm_graph[gi]); }
     if (h->comm) { try { (void)Rccl::get().destroy(h->comm); } catch (...) {} }
     for (int b = 0; b < 2; ++b) { if (h->ev_grad[b]) (void)hipEventDestroy(h->ev_grad[b]); if (h->ev_red[b]) (void)hipEventDestroy(h->ev_red[b]); }
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
@@ -2040,6 +2057,32 @@ int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev,
         };
         int i = 0;
         if (h->comm) {                  // data parallel: batches staged kMultiSteps at a time, then backward -> all-reduce -> Adam per bucket and step
+            // Runs of 16 (then 4) steps as ONE captured graph -- staging kernel, segments, ncclAllReduce on the comm stream (it
+            // joins the capture through the events), Adam per bucket -- so that the host is out of the loop exactly as in the
+            // single-replica path.  If RCCL refuses capture on this stack the host steps the same pipeline.
+            for (int gi = 0; gi < 2 && h->cfg.use_graph && !h->timing && !h->dp_graph_failed; ++gi)
+                for (; i + kMultiSizes[gi] <= n_steps; i += kMultiSizes[gi]) {
+                    if (!h->g_dpm[gi]) {
+                        std::vector<const float*> x0(h->M, h->at<float>(h->mods[0].X32));
+                        try {
+                            h->g_dpm[gi] = capture_with_prep(h, [&](hipStream_t cs) {
+                                const PrepArgs a = make_prep_batch(h, x0.data(), nullptr, nullptr, h->B, 0x7261696eull, kMultiSizes[gi]);
+                                launch_prep(h->cfg.compute_dtype, a, cs);
+                                LAUNCH_OK("prep");
+                                for (int j = 0; j < kMultiSizes[gi]; ++j) dp_step(h, j, cs, true);
+                            }, &h->g_dpm_graph[gi], &h->g_dpm_prep[gi]);
+                        } catch (const std::exception& e) {
+                            h->dp_graph_failed = true;
+                            h->g_dpm[gi] = nullptr;
+                            (void)hipGetLastError();
+                            if (std::getenv("AVAE_DEBUG_DP")) std::fprintf(stderr, "[avae] data-parallel graph capture failed (%s): host-stepped pipeline\n", e.what());
+                            break;
+                        }
+                    }
+                    const float* e = batch(i);
+                    patch_prep(h, h->g_dpm[gi], h->g_dpm_prep[gi], x.data(), x_ld, e, kMultiSizes[gi]);
+                    HIP_OK(hipGraphLaunch(h->g_dpm[gi], s));
+                }
             for (; i < n_steps; i += kMultiSteps) {
                 const int n = std::min(kMultiSteps, n_steps - i);
                 const float* e = batch(i);
