@@ -153,9 +153,60 @@ def launch_work(archs, B, es):
     return out, P
 
 
+def conv_stage_shapes(na):
+    """The nine stages of a hidden_conv modality (reference vae_assoc.py:169-199 encoder, :249-291 decoder, deconv.py:107-127) as
+    (name, kind, input pixels, output pixels, k, Cin, Cout): a conv multiplies per OUTPUT pixel k*k*Cin x Cout, a transposed conv
+    per INPUT pixel Cin x k*k*Cout (its algorithmic work: the zero-dilated form the patch-matrix route multiplies is 4x that for
+    stride 2), a dense layer is a 1-pixel conv.  SURVEY.md 8 rows A3/A4 give the same GEMM-equivalent shapes."""
+    r1, r2 = int(na["n_hidden_recog_1"]), int(na["n_hidden_recog_2"])
+    g1, g2 = int(na["n_hidden_gener_1"]), int(na["n_hidden_gener_2"])
+    nz, n_in = int(na["n_z"]), int(na["n_input"])
+    return [("enc1", "conv", 784, 196, 5, 1, r1), ("enc2", "conv", 196, 49, 5, r1, 2 * r1), ("enc3", "conv", 49, 9, 5, 2 * r1, r2),
+            ("head", "dense", 1, 1, 1, 9 * r2, 2 * nz),
+            ("dec1", "tconv", 1, 9, 3, nz, g1), ("dec2", "tconv", 9, 49, 5, g1, g1 // 2), ("dec3", "tconv", 49, 196, 5, g1 // 2, g2),
+            ("dec4", "tconv", 196, 784, 5, g2, 1), ("out", "dense", 1, 1, 1, n_in, n_in)]
+
+
 def conv_launch_work(archs, B, es):
-    """placeholder until the conv stages are priced: no per-launch model, parameters only"""
-    return {}, 0
+    """Algorithmic FLOPs and HBM bytes of one step of a model with a conv/deconv modality, per GEMM-like launch of
+    avae_host.hip::build_training_plan: MACs as conv_stage_shapes counts them (x2; forward, input gradient -- none for the first
+    conv, its input is data -- and filter gradient), bytes = the stage's input and output maps and its filter once each in the
+    compute type (fp32 for filter gradients and optimiser state).  The helper launches of the patch-matrix routes (im2col, col2im,
+    overlap-add, split-K reductions, adjoint filter shadows, permutes, row sums) do no algorithmic work: their time counts
+    against the step, their bytes are overhead."""
+    out = {}
+
+    def add(name, by, fl):
+        b0, f0 = out.get(name, (0, 0))
+        out[name] = (b0 + by, f0 + fl)
+    P = 0
+    for na in archs:
+        if not na.get("hidden_conv"):
+            w, p = launch_work([na], B, es)
+            for k, (by, fl) in w.items():
+                if k != "adam":
+                    add(k, by, fl)
+            P += p
+            continue
+        for name, kind, pin, pout, k, ci, co in conv_stage_shapes(na):
+            macs = (pout * k * k * ci * co) if kind == "conv" else (pin * k * k * ci * co)      # dense: pin = pout = k = 1
+            wts = k * k * ci * co + (0 if kind == "conv" else co)                                # convs carry no bias (vae_assoc.py:480-489)
+            P += wts
+            a_in, a_out = B * pin * ci, B * pout * co
+            fwd = {"enc1": "conv_enc1", "enc2": "conv_enc2", "enc3": "conv_enc3", "head": "fwd_head", "dec1": "conv_dec1",
+                   "dec2": "conv_dec2_scatter", "dec3": "conv_dec3_scatter", "dec4": "conv_dec4_direct", "out": "fwd_out_loss"}[name]
+            bwd = {"enc1": None, "enc2": "conv_bwd_enc2", "enc3": "conv_bwd_enc3", "head": "bwd_head", "dec1": "conv_dec1_latent",
+                   "dec2": "conv_bwd_dec2_adj", "dec3": "conv_bwd_dec3_adj", "dec4": "conv_bwd_dec4_direct", "out": "bwd_out"}[name]
+            wgr = "conv_dec4_wgrad_direct" if name == "dec4" else "wgrad"
+            add(fwd, (a_in + wts + a_out) * es + (a_out * 4 if name in ("head", "out") else 0), 2 * B * macs)
+            if bwd:
+                add(bwd, (a_out + wts + 2 * a_in) * es, 2 * B * macs)
+            add(wgr, (a_in + a_out) * es + wts * 4, 2 * B * macs)
+        add("fwd_out_loss", B * (2 + 3) * int(na["n_z"]) * 4, 0)
+        add("prep", B * int(na["n_input"]) * (4 + 4 + es), 0)
+    add("adam", 0, 0)
+    out["adam"] = (7 * P * 4 + P * es, 0)
+    return out, P
 
 
 def cpu_baseline(archs, B, budget_s=10.0):
@@ -206,7 +257,7 @@ def cpu_baseline(archs, B, budget_s=10.0):
     return out
 
 
-GEMM_LAUNCH_PREFIXES = ("fwd_enc", "fwd_dec", "fwd_head", "fwd_out_loss", "bwd_", "wgrad")
+GEMM_LAUNCH_PREFIXES = ("fwd_enc", "fwd_dec", "fwd_head", "fwd_out_loss", "bwd_", "wgrad", "conv_enc", "conv_dec", "conv_bwd")
 
 
 def measure(name, args, world, rank, local_rank, steps, warmup, repeats, kernel_steps, dtype=None):

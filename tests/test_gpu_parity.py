@@ -581,6 +581,36 @@ def test_transform_generate_reconstruct_rows(V):
     assert np.abs(model.get_params() - ref.get_params()).max() <= 2e-5
 
 
+def test_generate_serving_buckets(V):
+    """avae_generate (one graph replay per call: slot-indirect staging, grouped decoder launches of every modality, output move):
+    row counts on both sides of the 64-row serving bucket and of batch_size (chunked), interleaved with training steps that use the
+    same activation buffers; fp32 against the oracle, bf16 against the per-modality avae_decode path."""
+    import ctypes as C
+    archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
+    B = 160
+    model, ref = build_pair(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", B, "fp32")
+    rng = np.random.default_rng(18)
+    for rows in (1, 3, 64, 65, 160, 161, 400):
+        z = rng.standard_normal((rows, 20)).astype(np.float32)
+        gen, rgen = model.generate(z), ref.generate(z)
+        for m in range(2):
+            assert gen[m].shape == (rows, archs[m]["n_input"])
+            assert np.abs(gen[m] - rgen[m]).max() <= 1e-5 * max(1, np.abs(rgen[m]).max()), (rows, m)
+        if rows == 64:          # a training step in between must see intact padding / constant-1 columns
+            Xb = synth_batch(rng, B, [784, 147], [True, False])
+            eb = rng.standard_normal((B, 20)).astype(np.float32)
+            c, cr = model.partial_fit(Xb, eb), ref.partial_fit(Xb, eb)
+            assert abs(c - cr) <= 1e-5 * abs(cr)
+    mb = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="relu", batch_size=B, compute_dtype="bf16", seed=3)
+    for rows in (5, 64, 200):
+        z = torch.as_tensor(rng.standard_normal((rows, 20)).astype(np.float32)).cuda()
+        gen = mb.generate(z)
+        for m in range(2):
+            o = torch.empty((rows, archs[m]["n_input"]), dtype=torch.float32, device="cuda")
+            assert mb._L.avae_decode(mb._h, m, z.data_ptr(), rows, o.data_ptr(), mb._stream()) == 0
+            assert torch.equal(gen[m], o), (rows, m)
+
+
 def test_strided_modalities_from_one_matrix(V):
     """train() hands column slices of one [B, 931] matrix (vae_assoc.py:510,543): no copies."""
     archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]

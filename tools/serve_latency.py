@@ -15,6 +15,7 @@ g.build()
 import bench
 from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
 
+import ctypes as C
 archs, B, dtype, label = bench.CONFIGS["c2"]
 model = AssocVariationalAutoEncoder(archs, transfer_fct="relu", batch_size=B, compute_dtype=dtype, seed=0, **bench.HYPER)
 rng = np.random.default_rng(0)
@@ -32,3 +33,22 @@ for rows in (1, 64, 1024, 16384):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / n
         print("rows %6d  %-15s %8.1f us/call  %10.0f rows/s" % (rows, name, dt * 1e6, rows / dt))
+
+# the C ABI alone: avae_generate on preallocated outputs (what a C / C++ host pays per call; the Python rows above add two tensor
+# allocations and the ctypes marshalling)
+for rows in (1, 64):
+    z = torch.as_tensor(rng.standard_normal((rows, 20)).astype(np.float32)).cuda()
+    outs = [torch.empty((rows, int(na["n_input"])), dtype=torch.float32, device="cuda") for na in archs]
+    ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+    L, h, st, zp = model._L, model._h, model._stream(), z.data_ptr()
+    for _ in range(20):
+        L.avae_generate(h, zp, rows, ptrs, st)
+    torch.cuda.synchronize()
+    n = 2000
+    t = time.perf_counter()
+    for _ in range(n):
+        L.avae_generate(h, zp, rows, ptrs, st)
+    t_host = (time.perf_counter() - t) / n
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / n
+    print("rows %6d  C ABI, preallocated outputs: %6.1f us/call back to back (host side of a call: %.1f us)" % (rows, dt * 1e6, t_host * 1e6))

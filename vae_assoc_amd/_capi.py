@@ -28,7 +28,7 @@ SYMBOLS = [
     "avae_get_params", "avae_set_params", "avae_get_grads", "avae_get_opt_state", "avae_set_opt_state",
     "avae_train_step", "avae_train_steps", "avae_step_backward", "avae_step_apply", "avae_stage_batches", "avae_step_backward_staged", "avae_grad_buffer", "avae_cost_history",
     "avae_dp_plan", "avae_dp_backward", "avae_dp_apply", "avae_comm_unique_id",
-    "avae_eval_cost", "avae_encode", "avae_decode", "avae_reconstruct", "avae_save", "avae_load",
+    "avae_eval_cost", "avae_encode", "avae_decode", "avae_generate", "avae_reconstruct", "avae_save", "avae_load",
     "avae_synchronize", "avae_timing_enable", "avae_timing_report", "avae_debug_fetch",
 ]
 
@@ -95,6 +95,7 @@ def lib():
             L.avae_eval_cost.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), vp, fp, vp]
             L.avae_encode.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp]
             L.avae_decode.argtypes = [vp, i32, vp, i32, vp, vp]
+            L.avae_generate.argtypes = [vp, vp, i32, C.POINTER(vp), vp]
             L.avae_reconstruct.argtypes = [vp, i32, vp, i32, vp, i32, vp, vp]
             L.avae_save.argtypes = [vp, C.c_char_p]
             L.avae_load.argtypes = [vp, C.c_char_p]

@@ -263,6 +263,25 @@ struct RowsumSeg { const void* src; float* part; int ld, rows, cols, cols4, cpow
 struct RowsumArgs { RowsumSeg seg[2 * kMaxMod]; int n_seg; };
 void launch_rowsum(int compute_dtype, const RowsumArgs& a, int n_blocks, hipStream_t s);
 
+// Serving (avae_generate): the captured decode graph reads the caller's pointers and row count from this device-side slot (written
+// by one small hipMemcpyAsync per call), so that one graph serves every call without re-parameterising its nodes.
+struct ServeSlot {
+    const float* z;                // [rows][n_z] fp32, dense
+    float* out[kMaxMod];           // per modality [rows][n_input] fp32, dense
+    int rows;
+    int pad;
+};
+struct ServeArgs {
+    const ServeSlot* slot;
+    int n_mod, nz, bucket;         // rows of the captured plan (>= slot->rows)
+    void* Z[kMaxMod]; int ldz[kMaxMod];            // decoder inputs, compute dtype, [bucket][ldz]
+    const float* O[kMaxMod]; int ldo[kMaxMod]; int n_in[kMaxMod];   // decoder outputs (fp32 staging of the store kind)
+    int mode;                      // 0: z -> Z of every modality (rows beyond slot->rows zero);  1: O -> out rows
+    int blocks_per_mod;
+};
+void launch_serve(int compute_dtype, const ServeArgs& a, int n_blocks, hipStream_t s);
+void launch_set_slot(ServeSlot* dst, const ServeSlot& v, hipStream_t s);
+
 void launch_gather(int compute_dtype, const GatherArgs& a, int n_blocks, hipStream_t s);
 void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStream_t s);
 

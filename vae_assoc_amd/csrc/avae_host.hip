@@ -202,6 +202,11 @@ struct avae_handle {
     // inference tables: per modality, device slots at off_inf
     struct Inf { std::vector<WorkItem> items; std::vector<Launch> launches; int rows = -1; size_t dev_off = 0; };
     std::vector<Inf> inf_enc, inf_dec;
+    // serving (avae_generate): per row bucket one captured graph of [slot-indirect z staging, grouped decoder launches of all
+    // modalities, slot-indirect output move]
+    struct Serve { int bucket = 0; std::vector<WorkItem> items; std::vector<Launch> launches; hipGraphExec_t graph = nullptr; };
+    std::vector<Serve> serve;
+    size_t off_slot = 0;
 
     hipGraphExec_t g_full = nullptr, g_bwd = nullptr, g_eval = nullptr;
     hipGraphExec_t g_multi[2] = {nullptr, nullptr};   // kMultiSizes[i] whole steps per replay (avae_train_steps)
@@ -451,6 +456,7 @@ void plan_memory(avae_handle* h) {
     for (int m = 0; m < h->M; ++m) n_adam += h->mods[m].conv ? 9 : 2 * (size_t)h->mods[m].L + 2;
     h->off_adam = b.take(n_adam * sizeof(AdamItem));
     h->off_adam_b = b.take(n_adam * sizeof(AdamItem));
+    h->off_slot = b.take(sizeof(ServeSlot));
     h->off_inf = b.off;
     for (int m = 0; m < h->M; ++m) b.take(2 * ((size_t)h->mods[m].L + 1) * sizeof(WorkItem));
 #ifdef AVAE_STAMPS
@@ -1830,6 +1836,48 @@ void dp_step(avae_handle* h, int j, hipStream_t s, bool direct = false) {
     }
 }
 
+// ----------------------------------------------------------------------------- serving
+// generate() of every (MLP) modality as ONE graph replay per call (the reference's CEM / GUI callers decode
+// 10-50 times per iteration, baxter_vae_assoc_writer.py:141-147,259-304, vae_assoc_model_viewer.py:107-113).
+avae_handle::Serve& serve_plan(avae_handle* h, int bucket) {
+    for (avae_handle::Serve& sv : h->serve) if (sv.bucket == bucket) return sv;
+    h->serve.emplace_back();
+    avae_handle::Serve& sv = h->serve.back();
+    sv.bucket = bucket;
+    Builder bd(h, sv.items, bucket, false);
+    int slot = 0, Lmax = 0;
+    for (const Mod& md : h->mods) Lmax = std::max(Lmax, md.L);
+    auto group = [&](const std::string& name, auto&& fill) {
+        const int first = (int)sv.items.size();
+        fill();
+        const int count = (int)sv.items.size() - first;
+        if (count > 0) sv.launches.push_back(finish_launch(h, sv.items, first, count, name, &slot));
+    };
+    for (int k = 0; k < Lmax; ++k)
+        group("serve_dec" + std::to_string(k + 1), [&] { for (Mod& md : h->mods) if (k < md.L) sv.items.push_back(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k])); });
+    group("serve_out", [&] { for (int m = 0; m < h->M; ++m) sv.items.push_back(bd.fwd_out(h->mods[m], m, false)); });
+    ServeArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.slot = h->at<ServeSlot>(h->off_slot); a.n_mod = h->M; a.nz = h->nz; a.bucket = bucket;
+    for (int m = 0; m < h->M; ++m) {
+        const Mod& md = h->mods[m];
+        a.Z[m] = h->at<void>(md.Z.rm); a.ldz[m] = md.Z.ld;
+        a.O[m] = h->at<float>(md.out32); a.ldo[m] = md.ld32; a.n_in[m] = md.n_in;
+    }
+    auto body = [&](hipStream_t cs) {
+        ServeArgs in = a; in.mode = 0; in.blocks_per_mod = std::max(1, std::min(8, (bucket * h->nz + kThreads - 1) / kThreads));
+        launch_serve(h->cfg.compute_dtype, in, in.blocks_per_mod * h->M, cs); LAUNCH_OK("serve_in");
+        run_launches(h, sv.launches, cs);
+        ServeArgs out = a; out.mode = 1; out.blocks_per_mod = std::max(1, std::min(64, bucket / 4));
+        launch_serve(h->cfg.compute_dtype, out, out.blocks_per_mod * h->M, cs); LAUNCH_OK("serve_out_move");
+    };
+    const bool tsave = h->timing;
+    h->timing = false;
+    sv.graph = capture(h, body);
+    h->timing = tsave;
+    return sv;
+}
+
 }  // namespace
 
 // ============================================================================= C ABI
@@ -1902,6 +1950,7 @@ void avae_destroy(avae_handle* h) {
     for (hipGraphExec_t g : {h->g_full, h->g_multi[0], h->g_multi[1], h->g_bwd, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
     for (hipGraphExec_t g : h->g_bwd_set) if (g) (void)hipGraphExecDestroy(g);
     for (int b = 0; b < 2; ++b) for (hipGraphExec_t g : h->g_dp[b]) if (g) (void)hipGraphExecDestroy(g);
+    for (avae_handle::Serve& sv : h->serve) if (sv.graph) (void)hipGraphExecDestroy(sv.graph);
     for (int gi = 0; gi < 2; ++gi) { if (h->g_dpm[gi]) (void)hipGraphExecDestroy(h->g_dpm[gi]); if (h->g_dpm_graph[gi]) (void)hipGraphDestroy(h->g_dpm_graph[gi]); }
     if (h->comm) { try { (void)Rccl::get().destroy(h->comm); } catch (...) {} }
     for (int b = 0; b < 2; ++b) { if (h->ev_grad[b]) (void)hipEventDestroy(h->ev_grad[b]); if (h->ev_red[b]) (void)hipEventDestroy(h->ev_red[b]); }
@@ -2215,6 +2264,40 @@ int avae_decode(avae_handle* h, int32_t m, const float* z_dev, int32_t rows, flo
             run_prep_single(h, z_dev + (size_t)r0 * h->nz, h->nz, n, h->nz, md.Z, nullptr, 0, false, nullptr, 0, s);
             run_inference(h, m, false, n, s);
             copy_rows(xhat_dev + (size_t)r0 * md.n_in, (size_t)md.n_in * 4, h->at<float>(md.out32), (size_t)md.ld32 * 4, (size_t)md.n_in * 4, n, s);
+        }
+    });
+}
+
+int avae_generate(avae_handle* h, const float* z_dev, int32_t rows, float* const* xhat_dev, void* stream) {
+    return guarded(h, [&] {
+        if (rows < 0) throw Err("rows must be >= 0");
+        if (!z_dev || !xhat_dev) throw Err("null argument");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        bool any_conv = false;
+        for (const Mod& md : h->mods) any_conv = any_conv || md.conv;
+        if (any_conv || !h->cfg.use_graph || h->timing) {     // conv decoders (and the diagnostic modes) go modality by modality
+            for (int m = 0; m < h->M; ++m) {
+                const Mod& md = h->mods[m];
+                for (int r0 = 0; r0 < rows; r0 += h->B) {
+                    const int n = std::min(h->B, rows - r0);
+                    run_prep_single(h, z_dev + (size_t)r0 * h->nz, h->nz, n, h->nz, md.Z, nullptr, 0, false, nullptr, 0, s);
+                    build_inference(h, m, false, n);
+                    run_launches(h, h->inf_dec[m].launches, s);
+                    copy_rows(xhat_dev[m] + (size_t)r0 * md.n_in, (size_t)md.n_in * 4, h->at<float>(md.out32), (size_t)md.ld32 * 4, (size_t)md.n_in * 4, n, s);
+                }
+            }
+            return;
+        }
+        for (int r0 = 0; r0 < rows; r0 += h->B) {
+            const int n = std::min(h->B, rows - r0);
+            const int bucket = (n <= 64 && h->B > 64) ? 64 : h->B;       // the CEM / GUI callers' 1-64 rows, or a batch-sized chunk
+            avae_handle::Serve& sv = serve_plan(h, bucket);
+            ServeSlot sl;
+            std::memset(&sl, 0, sizeof(sl));
+            sl.z = z_dev + (size_t)r0 * h->nz; sl.rows = n;
+            for (int m = 0; m < h->M; ++m) sl.out[m] = xhat_dev[m] + (size_t)r0 * h->mods[m].n_in;
+            launch_set_slot(h->at<ServeSlot>(h->off_slot), sl, s); LAUNCH_OK("serve_slot");
+            HIP_OK(hipGraphLaunch(sv.graph, s));
         }
     });
 }

@@ -1864,6 +1864,41 @@ void launch_thin(int compute_dtype, const ThinArgs& a, int n_blocks, hipStream_t
     else AVAE_LAUNCH((k_thin<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
+// ------------------------------------------------------------------ serving: slot-indirect input / output moves
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_serve(ServeArgs a) {
+    const ServeSlot sl = *a.slot;
+    const int m = blockIdx.x / a.blocks_per_mod, b = blockIdx.x - m * a.blocks_per_mod;
+    if (a.mode == 0) {         // z rows -> Z[m] (compute dtype); padded rows of the bucket are written as zeros
+        const int total = a.bucket * a.nz;
+        for (int i = b * kThreads + threadIdx.x; i < total; i += a.blocks_per_mod * kThreads) {
+            const int r = i / a.nz, c = i - r * a.nz;
+            const float v = r < sl.rows ? sl.z[(size_t)r * a.nz + c] : 0.0f;
+            reinterpret_cast<CT*>(a.Z[m])[(size_t)r * a.ldz[m] + c] = to_ct<CT>(v);
+        }
+    } else {                   // decoder outputs -> the caller's dense [rows][n_input]
+        const int n4 = (a.n_in[m] + 3) >> 2, total = sl.rows * n4;
+        float* dst = sl.out[m];
+        for (int i = b * kThreads + threadIdx.x; i < total; i += a.blocks_per_mod * kThreads) {
+            const int r = i / n4, c = (i - r * n4) * 4;
+            float v[4];
+            load4<float>(a.O[m] + (size_t)r * a.ldo[m] + c, v);     // ldo % 8 == 0: in-row, aligned
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c + e < a.n_in[m]) dst[(size_t)r * a.n_in[m] + c + e] = v[e];
+        }
+    }
+}
+// the call's pointers and row count, by value -> the device slot the captured graph reads (a one-wave kernel: an H2D copy of 48
+// bytes goes through the copy engine and its stream hand-over, 28 -> 2x us per call measured on avae_generate)
+__global__ void k_set_slot(ServeSlot* dst, ServeSlot v) { if (threadIdx.x == 0) *dst = v; }
+void launch_set_slot(ServeSlot* dst, const ServeSlot& v, hipStream_t s) { AVAE_LAUNCH(k_set_slot, dim3(1), dim3(64), 0, s, dst, v); }
+
+void launch_serve(int compute_dtype, const ServeArgs& a, int n_blocks, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_serve<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else AVAE_LAUNCH((k_serve<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+}
+
 // ------------------------------------------------------------------ split-K reduction
 __global__ void __launch_bounds__(kThreads) k_reduce(ReduceArgs a) {
     const int bid = blockIdx.x;

@@ -443,14 +443,11 @@ class AssocVariationalAutoEncoder(object):
         z, was_np = self._dev(z_mu, self.n_z)
         z = z.contiguous()
         rows = z.shape[0]
-        outs = []
-        for m, na in enumerate(self.network_architectures):
-            o = torch.empty((rows, int(na["n_input"])), dtype=torch.float32, device=self.device)
-            if rows:
-                _capi.check(self._h, self._L.avae_decode(self._h, m, z.data_ptr(), rows, o.data_ptr(), self._stream()),
-                            "avae_decode")
-            outs.append(o.cpu().numpy() if was_np else o)
-        return outs
+        outs = [torch.empty((rows, int(na["n_input"])), dtype=torch.float32, device=self.device) for na in self.network_architectures]
+        if rows:       # every modality's decoder in one submission (avae_generate: one graph replay for 1-64 rows)
+            ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+            _capi.check(self._h, self._L.avae_generate(self._h, z.data_ptr(), rows, ptrs, self._stream()), "avae_generate")
+        return [o.cpu().numpy() for o in outs] if was_np else outs
 
     def reconstruct(self, X, eps=None):
         """Use VAE to reconstruct given data: encode -> sample z -> decode, per modality with its
