@@ -196,6 +196,13 @@ struct avae_handle {
     hipGraph_t g_dpm_graph[2] = {nullptr, nullptr};
     hipGraphNode_t g_dpm_prep[2] = {nullptr, nullptr};
     bool dp_graph_failed = false;           // RCCL refused stream capture on this stack: host-stepped pipeline instead
+    // Single-replica overlap inside the captured graphs (the same buckets): the decoder side's weight gradients + Adam run on a side
+    // stream from the moment bwd_dec1_latent is done, beside the encoder's backward pass, its weight gradients / Adam and -- in the
+    // multi-step graphs -- the NEXT step's encoder forward; the next step's first decoder launch waits for them.
+    bool overlap = false, ov_split_wgrad = false;
+    int fwd_dec_first = 0;                  // index in fwd of the first launch that reads decoder weights
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_side = nullptr;
     Launch cost_only;                       // eval: K_COST alone, no step bump
     std::vector<AdamItem> adam_items;
     int adam_blocks = 0;
@@ -1011,6 +1018,7 @@ void build_training_plan(avae_handle* h) {
         latent_alone = t64 >= 192 && t128 >= 192 && !narrow && !std::getenv("AVAE_NO_LOSS8");      // = finish_launch's choice of cfg 6
     }
     if (latent_alone) group("latent", h->fwd, [&] { h->items.push_back(bd.latent()); });
+    h->fwd_dec_first = (int)h->fwd.size();
     for (int k = 0; k < std::max(Lmax, 1); ++k)
         group("fwd_dec" + std::to_string(k + 1), h->fwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k]));
@@ -1195,6 +1203,15 @@ void build_training_plan(avae_handle* h) {
             h->ranges_b[0].back().count += 1;                    // + the step's cost (final since bwd_dec1_latent)
             wgrad_launches(set[0], h->wgrad_b[0], "wgrad_dec");
             wgrad_launches(set[1], h->wgrad_b[1], "wgrad_enc");
+            long wide = 0;
+            for (const WorkItem& w : wg) if (!is_narrow(w)) wide += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
+            // Measured and switched off (AVAE_OVERLAP=1 turns it on, results are bitwise the same): C2 95.8 vs 64.1 us/step, C4 0.616
+            // vs 0.587 ms -- in the single-replica graphs the fork / join edges cost far more than the ~8 us of Adam they hide (the
+            // data-parallel graph, where the side stream carries the RCCL kernels, does gain: 71 us with the extra collective work).
+            h->overlap = std::getenv("AVAE_OVERLAP") != nullptr;
+            // small nets: the weight-gradient launch is a fraction of a round of the chip and splits for free; big nets keep it whole
+            // (C4: 134 us as one launch, 111 + 119 as two) and only Adam is cut
+            h->ov_split_wgrad = wide < 192;
         } else {
             h->ranges_b[0].push_back({0, h->P_int + 1});
         }
@@ -1638,11 +1655,56 @@ void init_device(avae_handle* h) {
         h->timing = false;
         h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, h->bwd, cs); run_launches(h, h->wgrad, cs); });
         std::vector<const float*> x0(h->M, h->at<float>(h->mods[0].X32));    // placeholders, patched per step
+        if (h->overlap && h->n_buckets == 2) {
+            HIP_OK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+        } else {
+            h->overlap = false;
+        }
+        // one step on staging set j inside a capture; `pending` = the side stream still carries the previous step's decoder bucket
+        auto step_body = [&](hipStream_t cs, int j, bool& pending, int stamp_base) {
+            auto run = [&](const std::vector<Launch>& ls, size_t lo, size_t hi, hipStream_t st, int sb) {
+                std::vector<Launch> moved;
+                for (size_t i = lo; i < hi && i < ls.size(); ++i) moved.push_back(relocated(h, ls[i], j));
+                run_launches(h, moved, st, sb);
+            };
+            if (!h->overlap) {
+                run(h->fwd, 0, h->fwd.size(), cs, stamp_base); run(h->bwd, 0, h->bwd.size(), cs, stamp_base < 0 ? -1 : stamp_base + (int)h->fwd.size());
+                run(h->wgrad, 0, h->wgrad.size(), cs, stamp_base < 0 ? -1 : stamp_base + (int)(h->fwd.size() + h->bwd.size()));
+                run_adam(h, 0, cs);
+                return;
+            }
+            run(h->fwd, 0, (size_t)h->fwd_dec_first, cs, -1);
+            if (pending) { HIP_OK(hipStreamWaitEvent(cs, h->ev_side, 0)); pending = false; }      // decoder weights of the previous step are final
+            run(h->fwd, (size_t)h->fwd_dec_first, h->fwd.size(), cs, -1);
+            run(h->bwd, 0, (size_t)h->bwd_split, cs, -1);
+            if (h->ov_split_wgrad) {
+                HIP_OK(hipEventRecord(h->ev_fork, cs));
+                HIP_OK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+                run(h->wgrad_b[0], 0, h->wgrad_b[0].size(), h->side_stream, -1);
+                run_adam(h, 0, h->side_stream, 0);
+                HIP_OK(hipEventRecord(h->ev_side, h->side_stream));
+                run(h->bwd, (size_t)h->bwd_split, h->bwd.size(), cs, -1);
+                run(h->wgrad_b[1], 0, h->wgrad_b[1].size(), cs, -1);
+                run_adam(h, 0, cs, 1);
+            } else {        // Adam of the encoder side first and alone (it is HBM-bound: two at once gain nothing), then the decoder side's beside
+                            // the next step's encoder forward (MFMA-bound launches with register-file room for Adam's small waves)
+                run(h->bwd, (size_t)h->bwd_split, h->bwd.size(), cs, -1);
+                run(h->wgrad, 0, h->wgrad.size(), cs, -1);
+                run_adam(h, 0, cs, 1);
+                HIP_OK(hipEventRecord(h->ev_fork, cs));
+                HIP_OK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+                run_adam(h, 0, h->side_stream, 0);
+                HIP_OK(hipEventRecord(h->ev_side, h->side_stream));
+            }
+            pending = true;
+        };
         auto one_step = [&](hipStream_t cs) {
             run_prep_batch(h, x0.data(), nullptr, nullptr, h->B, 0x7261696eull, cs);
-            run_launches(h, h->fwd, cs, 0); run_launches(h, h->bwd, cs, (int)h->fwd.size());
-            run_launches(h, h->wgrad, cs, (int)(h->fwd.size() + h->bwd.size()));
-            run_adam(h, 0, cs);
+            bool pending = false;
+            step_body(cs, 0, pending, 0);
+            if (pending) HIP_OK(hipStreamWaitEvent(cs, h->ev_side, 0));
         };
         h->g_full = capture_with_prep(h, one_step, &h->g_full_graph, &h->g_full_prep);
         // avae_train_steps: kMultiSteps whole steps per replay (a replay boundary costs ~5 us of idle GPU on this stack),
@@ -1651,14 +1713,9 @@ void init_device(avae_handle* h) {
             const PrepArgs a = make_prep_batch(h, x0.data(), nullptr, nullptr, h->B, 0x7261696eull, kMultiSizes[gi]);
             launch_prep(h->cfg.compute_dtype, a, cs);
             LAUNCH_OK("prep");
-            for (int j = 0; j < kMultiSizes[gi]; ++j) {
-                for (const std::vector<Launch>* ls : {&h->fwd, &h->bwd, &h->wgrad}) {
-                    std::vector<Launch> moved;
-                    for (const Launch& L : *ls) moved.push_back(relocated(h, L, j));
-                    run_launches(h, moved, cs);
-                }
-                run_adam(h, 0, cs);
-            }
+            bool pending = false;
+            for (int j = 0; j < kMultiSizes[gi]; ++j) step_body(cs, j, pending, -1);
+            if (pending) HIP_OK(hipStreamWaitEvent(cs, h->ev_side, 0));        // join before the graph ends
         }, &h->g_multi_graph[gi], &h->g_multi_prep[gi]);
         h->g_eval = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, std::vector<Launch>{h->cost_only}, cs); });
         h->timing = tsave;
@@ -1951,6 +2008,9 @@ void avae_destroy(avae_handle* h) {
     for (hipGraphExec_t g : h->g_bwd_set) if (g) (void)hipGraphExecDestroy(g);
     for (int b = 0; b < 2; ++b) for (hipGraphExec_t g : h->g_dp[b]) if (g) (void)hipGraphExecDestroy(g);
     for (avae_handle::Serve& sv : h->serve) if (sv.graph) (void)hipGraphExecDestroy(sv.graph);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     for (int gi = 0; gi < 2; ++gi) { if (h->g_dpm[gi]) (void)hipGraphExecDestroy(h->g_dpm[gi]); if (h->g_dpm_graph[gi]) (void)hipGraphDestroy(h->g_dpm_graph[gi]); }
     if (h->comm) { try { (void)Rccl::get().destroy(h->comm); } catch (...) {} }
     for (int b = 0; b < 2; ++b) { if (h->ev_grad[b]) (void)hipEventDestroy(h->ev_grad[b]); if (h->ev_red[b]) (void)hipEventDestroy(h->ev_red[b]); }
