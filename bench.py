@@ -480,6 +480,7 @@ def main():
             "step_roofline": pr["step_roofline"],
             "gemm_launches": {k: v for k, v in pr["gemm_launches"].items() if k != "per_launch"},
             "kernels_us": {n: round(v[1] * 1e3, 2) for n, v in sorted(res["kern"].items())},
+            "launch_order": [n for n in res["kern"] if n not in ("prep", "_null_kernel")],      # one step's launches in issue order (tools/per_launch.py)
             "last_cost": res["last_cost"],
         }
         if extras:

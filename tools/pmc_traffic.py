@@ -42,7 +42,9 @@ def per_position(counter, sub):
 fetch = per_position("FETCH_SIZE", "fetch")
 write = per_position("WRITE_SIZE", "write")
 L = len(archs[0]["n_hidden"])
-names = (["fwd_enc%d" % (k + 1) for k in range(L)] + ["fwd_head"] + ["fwd_dec%d" % (k + 1) for k in range(L)] + ["fwd_out_loss", "bwd_out"]
+cd = lambda a, b: -(-a // b)
+latent_alone = (sum(cd(B, 256) * cd(na["n_input"], 64) for na in archs) >= 192 and sum(cd(B, 128) * cd(na["n_input"], 128) for na in archs) >= 192)
+names = (["fwd_enc%d" % (k + 1) for k in range(L)] + ["fwd_head"] + (["latent"] if latent_alone else []) + ["fwd_dec%d" % (k + 1) for k in range(L)] + ["fwd_out_loss", "bwd_out"]
          + ["bwd_dec%d" % (k + 1) for k in range(L - 1, 0, -1)] + ["bwd_dec1_latent", "bwd_head"]
          + ["bwd_enc%d" % (k + 1) for k in range(L - 1, 0, -1)])
 n_wg = len([k for k in fetch if k != "prep"]) - len(names) - 1            # the step ends with k_adam
