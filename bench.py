@@ -334,7 +334,7 @@ def measure(name, args, world, rank, local_rank, steps, warmup, repeats, kernel_
 
     # ---- per-kernel device time: eager launches, each stamped by hipExtLaunchKernel start/stop events on the launch stream
     kern = {}
-    if rank == 0 and kernel_steps > 0:
+    if kernel_steps > 0:               # EVERY rank takes the steps (under data parallelism each step carries a collective); rank 0 reports
         L, h = model._L, model._h
         L.avae_timing_enable(h, 1)
         for i in range(kernel_steps):
@@ -342,7 +342,7 @@ def measure(name, args, world, rank, local_rank, steps, warmup, repeats, kernel_
         buf = C.create_string_buffer(1 << 16)
         L.avae_timing_report(h, buf, len(buf))
         L.avae_timing_enable(h, 0)
-        for line in buf.value.decode().splitlines():
+        for line in (buf.value.decode().splitlines() if rank == 0 else []):
             nm, calls, avg_ms, min_ms = line.split()
             base = nm.split(".")[0]          # large problems run one launch per modality: "<name>", "<name>.1", ...
             c0, a0, m0 = kern.get(base, (0, 0.0, 0.0))
@@ -359,6 +359,11 @@ def measure(name, args, world, rank, local_rank, steps, warmup, repeats, kernel_
 def price(res):
     """roofline of the dominant launch + step-level fractions + the GEMM launches' MFMA fraction, from measure()'s result"""
     archs, B, es, kern, dt, steps = res["archs"], res["B"], res["es"], res["kern"], res["dt"], res["steps"]
+    kern = dict(kern)
+    for whole in ("wgrad", "adam"):       # data-parallel pipeline: the launch runs once per gradient bucket
+        parts = [n for n in kern if n.startswith(whole + "_")]
+        if parts and whole not in kern:
+            kern[whole] = (max(kern[n][0] for n in parts), sum(kern[n][1] for n in parts), sum(kern[n][2] for n in parts))
     peak_tf = MFMA_BF16_PEAK_TF if es == 2 else MFMA_F32_PEAK_TF
     work, P = launch_work(archs, B, es)
     names = [n for n in kern if n in work]
