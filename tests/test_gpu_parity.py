@@ -458,6 +458,19 @@ def test_planner_switches_big_launches(V, monkeypatch, env):
     check_step_parity(V, archs, [True, False], [5.0, 1.0], 0.5, "softplus", 4096, "bf16", steps=1)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fused_narrow_layer_route(V, monkeypatch, dtype):
+    """AVAE_FUSE=1 (opt-in; slower than the two launches it replaces) folds the decoder's first layer into the
+    prologue of the second and the heads' input gradient into the last encoder layer's dgrad (k_fused32): same parity against
+    the oracle, and the first step's gradients agree with the default route's to fp32 rounding."""
+    archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
+    base, _e, _X, _eps = check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", 256, dtype, steps=1)
+    monkeypatch.setenv("AVAE_FUSE", "1")
+    fused, _e, _X, _eps = check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", 256, dtype, steps=1)
+    gb, gf = base.get_grads(), fused.get_grads()
+    assert np.abs(gb - gf).max() <= (1e-6 if dtype == "fp32" else 2e-3) * np.abs(gb).max()
+
+
 @pytest.mark.parametrize("env", [{"AVAE_NO_THIN": "1"}, {"AVAE_NO_ADJ": "1"}, {"AVAE_NO_THIN": "1", "AVAE_NO_ADJ": "1"}])
 def test_planner_switches_conv_routes(V, monkeypatch, env):
     """Conv stages through the patch-matrix route instead of the direct / adjoint-frame ones: same parity."""

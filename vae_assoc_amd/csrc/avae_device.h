@@ -70,6 +70,17 @@ struct WorkItem {
     float* partial;          // cost partial slots
     const float* eps;        // K_LATENT: the step's eps [B][ldx]
     float wts[kMaxMod];      // K_LATENT: per-modality cost weights
+    // Fused producer (k_fused32, small nets): the A operand of this product is itself a narrow product that used to be a launch of
+    // its own -- forward: A = act(Xs . Ws^T) (the decoder's first layer, K = n_z + 1); dgrad: A = (Xs . Ws^T) * act'(aux) (the head's
+    // input gradient, K = 2 n_z).  Every workgroup recomputes its 32 rows of A into LDS; the workgroups of column tile 0 also store them.
+    const void* pro_x;       // Xs  [rows][pro_ldx]   (z with its constant-1 column, or dH)
+    const void* pro_w;       // Ws  [units][pro_ldw]  (K-contiguous weight shadow of the narrow layer)
+    void* pro_out;           // where A's rows go in HBM (the buffer the separate launch used to write), leading dim lda
+    const void* pro_aux;     // dgrad: stored output of the layer A's gradient belongs to [rows][pro_lda2]
+    int pro_mode;            // 0: none; 1: forward; 2: dgrad
+    int pro_u;               // valid units (columns of A)
+    int pro_ldx, pro_ldw, pro_lda2;
+    int pro_act, pro_ones;   // transfer function; 1: A carries a constant-1 column at index pro_u
     // K_LATENT reuses the pointer fields: [mu|lv] inputs of modality 0..3 = A, B, aux0, aux1;
     // static-gradient outputs g0 of modality 0..3 = out0, out1, out2, aux2.
     // K_COST: scale = lr, lambda = beta1, inv_bg = beta2 (it also publishes this step's Adam lr_t).
@@ -295,6 +306,8 @@ constexpr int kStampLaunches = 32, kStampBlocks = 1024, kStampWords = 8;
 
 // launchers implemented in avae_kernels.hip
 int tile_lds_bytes(int tile_cfg, bool two_c_tiles);
+int fused32_lds_bytes(int es, int k_main_elems);          // LDS of k_fused32 for a main product of K (padded) elements
+void launch_fused32(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s);
 void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
                     DevState* st, hipStream_t s, unsigned long long* stamps = nullptr, int launch_id = 0);
 void launch_grouped_tn(int compute_dtype, int tile_cfg, const TnLaunchArgs& args, int grid_x, int grid_y, int lds_bytes,

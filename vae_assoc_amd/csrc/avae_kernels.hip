@@ -1227,6 +1227,193 @@ void launch_grouped_tn(int compute_dtype, int tile_cfg, const TnLaunchArgs& args
 }
 #undef AVAE_GO
 
+// ------------------------------------------------------------------ small nets: narrow layer fused into its consumer's prologue
+// C1 / C2 / C3 / C5 run a chain of ~4-us launches whose K loops are a fraction of that; two of them multiply over a single K tile
+// (the decoder's first layer, K = n_z + 1, and the heads' input gradient, K = 2 n_z) and are pure launch overhead.  k_fused32 is
+// the 32x32-tile product (4 waves, 4-stage LDS-DMA ring, k_grouped's NT conventions: 128-byte rows, chunk c of row r at
+// c ^ ((r >> 1) & 7)) whose A operand never comes from HBM: every workgroup first DMAs the narrow layer's input rows (32 x 128 B)
+// and its whole weight shadow (units x 128 B) into LDS, multiplies them (swapped MFMA operands: row on the lane, 4 consecutive
+// units in the registers), applies the transfer function (forward) or act'(stored output) (dgrad) and writes the 32 x K result into
+// LDS in the K-tile image the main loop's A fragments are read from; workgroups of column tile 0 also store it to HBM, where the
+// backward pass and the weight gradients expect it.  The main loop then streams only the B operand.  Bitwise the separate launches'
+// results (same products, same K order, same rounding points).
+int fused32_lds_bytes(int es, int k_main_elems) {
+    const int nk = k_main_elems * es / kTileBytesK;           // K tiles of the main product = 128-byte rows of A per tile row
+    return 4 * 32 * kTileBytesK                               // B ring
+         + 32 * kTileBytesK                                   // Xs
+         + nk * (kTileBytesK / es) * kTileBytesK              // Ws: one 128-byte row per unit, units padded to whole K tiles
+         + nk * 32 * kTileBytesK                              // resident A
+         + 64;
+}
+
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_fused32(const LaunchArgs args, int lds_bytes) {
+    constexpr int BM = 32, BN = 32, RING = 4, ES = (int)sizeof(CT), EPR = kTileBytesK / ES, LDC = BN + 4;
+    constexpr int kStageB = BN * kTileBytesK;                 // a ring stage holds the B part only
+    unsigned char* smem = avae_dyn_smem;
+    // item and tile (k_grouped's XCD-aware order)
+    const int part = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const WorkItem w = args.items[blockIdx.y];
+    asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.aux0), "s"(w.pro_x), "s"(w.pro_w), "s"(w.pro_out), "s"(w.K), "s"(w.ldb), "s"(w.ld0));
+    int t;
+    {
+        const int nt = w.tiles_m * w.tiles_n;
+        const int q = nt / 8, r = nt - q * 8;
+        if (idx >= q + (part < r ? 1 : 0)) return;
+        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tm = t / w.tiles_n, tn = t - tm * w.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = (w.K * ES) / kTileBytesK;
+    const int units_p = nk * EPR;                             // units of the narrow layer, padded to whole K tiles
+    unsigned char* Xs = smem + RING * kStageB;
+    unsigned char* Ws = Xs + 32 * kTileBytesK;
+    unsigned char* Ar = Ws + (size_t)units_p * kTileBytesK;
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    const int prow = lane >> 3;                               // row of a DMA piece this lane fetches (8 rows x 128 B per piece)
+    // ---- prologue DMAs: Xs (4 pieces), Ws (units_p / 8 pieces), then the first RING-1 B tiles (one piece per wave and tile)
+    {
+        const unsigned char* xg = reinterpret_cast<const unsigned char*>(w.pro_x) + (size_t)m0 * w.pro_ldx * ES;
+        const int r = wave_u * 8 + prow;                      // piece `wave` = rows 8*wave ..
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((gp_t)(xg + (size_t)r * w.pro_ldx * ES + lc * 16), (lp_t)(Xs + wave_u * 1024), 16, 0, 0);
+    }
+    const int n_wp = units_p / 8;                             // pieces of Ws; piece p goes to wave p % 4
+    for (int p = wave_u; p < n_wp; p += 4) {
+        const int r = p * 8 + prow;
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((gp_t)(reinterpret_cast<const unsigned char*>(w.pro_w) + (size_t)r * w.pro_ldw * ES + lc * 16),
+                                         (lp_t)(Ws + p * 1024), 16, 0, 0);
+    }
+    const unsigned char* Bg = reinterpret_cast<const unsigned char*>(w.B) + (size_t)n0 * w.ldb * ES;
+    const unsigned char* bsrc;                                // this wave's piece of a B tile: rows 8*wave ..
+    {
+        const int r = wave_u * 8 + prow;
+        bsrc = Bg + (size_t)r * w.ldb * ES + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+    }
+#define AVAE_F_DMA(kt, buf) __builtin_amdgcn_global_load_lds((gp_t)(bsrc + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kStageB + wave_u * 1024), 16, 0, 0)
+    const int npro = nk < RING - 1 ? nk : RING - 1;
+    for (int p = 0; p < npro; ++p) AVAE_F_DMA(p, p);
+    // epilogue-side operand of the dgrad producer: stored output of the layer (act'), 4 units per lane and unit tile, in flight meanwhile
+    // ---- the narrow product: wave (wr, wc) owns rows 16 wr .. and the unit tiles g with g % 2 == wc
+    // Xs / Ws have landed once only the B tiles issued behind them are outstanding (<= 3 pieces per wave)
+    if (npro == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (npro == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    const int sw0 = (fq ^ (fr >> 1)) * 16;
+    {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(Xs + (wr * 16 + fr) * kTileBytesK + sw0);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(Xs + (wr * 16 + fr) * kTileBytesK + (sw0 ^ 64));
+        const int row = wr * 16 + fr;                         // row of the tile this lane holds (swapped operands), units 4 fq ..
+        const int grow = m0 + row;
+        const int n_ut = units_p / 16;
+        const bool store_a = tn == 0 && grow < w.M;
+        // A wave owns at most kMaxG unit tiles (units_p <= 512).  The loops below are fully unrolled and branch-free up to the stores
+        // (a unit tile beyond the wave's last one is the last one computed again), so that all fragment reads -- and, for the
+        // dgrad producer, all 16 loads of the stored activations -- are in flight together instead of one round trip per tile.
+        constexpr int kMaxG = 16;
+        const int g_last = n_ut - 2 + wc;                     // this wave's last unit tile (n_ut is a multiple of 4)
+        typename Quad<CT>::raw yq[kMaxG];
+        if (w.pro_mode == 2) {
+            const CT* ybase = reinterpret_cast<const CT*>(w.pro_aux) + (size_t)min(grow, w.M - 1) * w.pro_lda2;
+#pragma unroll
+            for (int gi = 0; gi < kMaxG; ++gi) {
+                const int g = min(wc + 2 * gi, g_last);
+                yq[gi] = *reinterpret_cast<const typename Quad<CT>::raw*>(ybase + min(g * 16 + 4 * fq, w.pro_lda2 - 4));
+            }
+        }
+        f32x4 pacc[kMaxG];
+#pragma unroll
+        for (int gi = 0; gi < kMaxG; ++gi) {
+            const int g = min(wc + 2 * gi, g_last);
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(Ws + (g * 16 + fr) * kTileBytesK + sw0);
+            const u32x4 b1 = *reinterpret_cast<const u32x4*>(Ws + (g * 16 + fr) * kTileBytesK + (sw0 ^ 64));
+            pacc[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma<CT>(b0, a0, pacc[gi]);                        // swapped: pacc[gi][r] = A[row][unit0 + r]
+            mma<CT>(b1, a1, pacc[gi]);
+        }
+#pragma unroll
+        for (int gi = 0; gi < kMaxG; ++gi) {
+            const int g = wc + 2 * gi;
+            const int unit0 = min(g, g_last) * 16 + 4 * fq;
+            float v[4];
+            if (w.pro_mode == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = unit0 + r < w.pro_u ? pacc[gi][r] * act_bwd(w.pro_act, quad_elem<CT>(yq[gi], r)) : 0.0f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = unit0 + r < w.pro_u ? act_fwd(w.pro_act, pacc[gi][r]) : ((w.pro_ones && unit0 + r == w.pro_u) ? 1.0f : 0.0f);
+            }
+            if (g <= g_last) {
+                // into the resident A image: K tile kt = unit / EPR, 16-byte chunk (unit % EPR) * ES / 16, swizzled by the row
+                const int kt = unit0 / EPR, ub = (unit0 - kt * EPR) * ES;
+                unsigned char* dst = Ar + (size_t)kt * (32 * kTileBytesK) + row * kTileBytesK + ((((ub >> 4) ^ ((row >> 1) & 7)) << 4) | (ub & 15));
+                if constexpr (sizeof(CT) == 2) {
+                    const bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(dst) = pk;
+                } else {
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                }
+                if (store_a && unit0 < w.pro_u)                // (the constant-1 column of the HBM copy was set at create and is never written)
+                    store_row<CT>(reinterpret_cast<CT*>(w.pro_out) + (size_t)grow * w.lda + unit0, v, w.pro_u - unit0);
+            }
+        }
+    }
+    // ---- main K loop: A fragments from the resident image, B through the ring (one piece per wave and tile)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int aoff = (wr * 16 + fr) * kTileBytesK, boff = (wc * 16 + fr) * kTileBytesK;
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt, nb = rem < RING - 2 ? rem : RING - 2;
+        if (nb == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (nb == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                        // (kt = 0: also orders the A image written above)
+        const unsigned char* Sb = smem + buf * kStageB;
+        const unsigned char* Sa = Ar + (size_t)kt * (32 * kTileBytesK);
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(Sa + aoff + sw0), b0 = *reinterpret_cast<const u32x4*>(Sb + boff + sw0);
+        const int fill = buf == 0 ? RING - 1 : buf - 1;
+        if (kt + RING - 1 < nk) AVAE_F_DMA(kt + RING - 1, fill);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(Sa + aoff + (sw0 ^ 64)), b1 = *reinterpret_cast<const u32x4*>(Sb + boff + (sw0 ^ 64));
+        mma<CT>(a0, b0, acc);
+        mma<CT>(a1, b1, acc);
+        buf = buf + 1 == RING ? 0 : buf + 1;
+    }
+#undef AVAE_F_DMA
+    lds_barrier();
+    // ---- epilogue: k_grouped's LDS-staged passes (the ring is free now)
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cs[cs_idx<LDC>(wr * 16 + fq * 4 + r, wc * 16 + fr)] = acc[r];
+    lds_barrier();
+    const int M = w.M, N = w.N;
+    if (w.kind == K_FWD_HIDDEN) {
+        CT* Y = reinterpret_cast<CT*>(w.out0);
+        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, false, false, BM, BN>(Cs, Y, w.ld0, (const CT*)nullptr, 4, M, N, m0, n0,
+            [](float c, float, bool) { return act_fwd_t<ACT>(c); })))
+    } else {                 // K_DGRAD_HIDDEN
+        CT* dX = reinterpret_cast<CT*>(w.out0);
+        const CT* Yp = reinterpret_cast<const CT*>(w.aux0);
+        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, true, false, BM, BN>(Cs, dX, w.ld0, Yp, w.ldx, M, N, m0, n0,
+            [](float c, float y, bool) { return c * act_bwd_t<ACT>(y); })))
+    }
+}
+
+void launch_fused32(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s) {
+    static const bool once = [] {
+        set_max_lds(k_fused32<__bf16>); set_max_lds(k_fused32<float>);
+        return true;
+    }();
+    (void)once;
+    dim3 grid(grid_x, grid_y), block(kThreads);
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_fused32<__bf16>), grid, block, lds_bytes, s, args, lds_bytes);
+    else AVAE_LAUNCH((k_fused32<float>), grid, block, lds_bytes, s, args, lds_bytes);
+}
+
 // ------------------------------------------------------------------ Adam + shadow refresh
 // TF-1 AdamOptimizer dense update (reference vae_assoc.py:373-374; TF training_ops ApplyAdam):
 //   lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m += (g-m)(1-b1);  v += (g^2-v)(1-b2);
