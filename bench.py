@@ -366,6 +366,11 @@ def price(res):
             kern[whole] = (max(kern[n][0] for n in parts), sum(kern[n][1] for n in parts), sum(kern[n][2] for n in parts))
     peak_tf = MFMA_BF16_PEAK_TF if es == 2 else MFMA_F32_PEAK_TF
     work, P = launch_work(archs, B, es)
+    for n in list(kern):                  # "a+b": launch b rides in launch a as its tail product (avae_host.hip::fuse_tail)
+        parts = n.split("+")
+        if len(parts) > 1 and all(p in work for p in parts):
+            vals = [work.pop(p) for p in parts]
+            work[n] = (sum(v[0] for v in vals), sum(v[1] for v in vals))
     names = [n for n in kern if n in work]
     step_us = dt / steps * 1e6
     dom = max(names, key=lambda n: kern[n][1]) if names else None

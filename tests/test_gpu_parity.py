@@ -459,16 +459,28 @@ def test_planner_switches_big_launches(V, monkeypatch, env):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_fused_narrow_layer_route(V, monkeypatch, dtype):
-    """AVAE_FUSE=1 (opt-in; slower than the two launches it replaces) folds the decoder's first layer into the
-    prologue of the second and the heads' input gradient into the last encoder layer's dgrad (k_fused32): same parity against
-    the oracle, and the first step's gradients agree with the default route's to fp32 rounding."""
+@pytest.mark.parametrize("B", [256, 100])
+def test_tail_product_route(V, monkeypatch, dtype, B):
+    """Small nets: the decoder's first layer rides in the heads' launch and the heads' input gradient in bwd_dec1_latent's (the
+    tail product of the 32x64 head tiles, avae_host.hip::fuse_tail).  Default route = tail on; AVAE_NO_TAIL=1 = the four
+    separate launches.  Both pass the oracle parity, and they agree with each other bitwise after a step (same products,
+    same K order, same rounding points).  B = 100: a last, partial row tile."""
     archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
-    base, _e, _X, _eps = check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", 256, dtype, steps=1)
-    monkeypatch.setenv("AVAE_FUSE", "1")
-    fused, _e, _X, _eps = check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", 256, dtype, steps=1)
-    gb, gf = base.get_grads(), fused.get_grads()
-    assert np.abs(gb - gf).max() <= (1e-6 if dtype == "fp32" else 2e-3) * np.abs(gb).max()
+    on, _e, _X, _eps = check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", B, dtype, steps=1)
+    import ctypes as C
+    L, h = on._L, on._h
+    assert L.avae_timing_enable(h, 1) == 0
+    on.partial_fit(_X, _eps[0])
+    buf = C.create_string_buffer(1 << 16)
+    assert L.avae_timing_report(h, buf, len(buf)) == 0 and L.avae_timing_enable(h, 0) == 0
+    names = [ln.split()[0] for ln in buf.value.decode().splitlines()]
+    monkeypatch.setenv("AVAE_NO_TAIL", "1")
+    off, _e, _X, _eps = check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", B, dtype, steps=1)
+    off.partial_fit(_X, _eps[0])             # (the second step `on` took under the timer)
+    assert np.array_equal(on.get_grads(), off.get_grads())
+    assert np.array_equal(on.get_params(), off.get_params())
+    assert "fwd_head+fwd_dec1" in names, names
+    assert "bwd_dec1_latent+bwd_head" in names, names      # ([dmu | dlv] = 40 columns: one 128-byte K tile of bf16, two of fp32)
 
 
 @pytest.mark.parametrize("env", [{"AVAE_NO_THIN": "1"}, {"AVAE_NO_ADJ": "1"}, {"AVAE_NO_THIN": "1", "AVAE_NO_ADJ": "1"}])

@@ -46,6 +46,9 @@ def main():
     st = buf.reshape(nl, nb, nw).astype(np.int64)
     names = ['fwd_enc1', 'fwd_enc2', 'fwd_head', 'fwd_dec1', 'fwd_dec2', 'fwd_out_loss', 'bwd_out', 'bwd_dec2',
              'bwd_dec1_latent', 'bwd_head', 'bwd_enc2', 'wgrad']
+    if cfg != "c4" and not os.environ.get("AVAE_NO_TAIL"):      # tail products: two launches fewer (avae_host.hip::fuse_tail)
+        names = ['fwd_enc1', 'fwd_enc2', 'fwd_head+fwd_dec1', 'fwd_dec2', 'fwd_out_loss', 'bwd_out', 'bwd_dec2',
+                 'bwd_dec1_latent+bwd_head', 'bwd_enc2', 'wgrad']
     print("%-16s %6s %8s | %7s %7s %7s %7s | %8s %7s  (us; realtime ticks are 10 ns)" % (
         "launch", "blocks", "span", "lookup", "tile0", "kloop", "epilog", "startspr", "clkMHz"))
     prev_end = None
@@ -71,7 +74,10 @@ def main():
         ep = "acc->lds %.2f pass1 %.2f rest %.2f" % (((e1[:, 5] - e1[:, 3]).mean() / 100.0), ((e1[:, 6] - e1[:, 5]).mean() / 100.0),
                                                      ((e1[:, 4] - e1[:, 6]).mean() / 100.0)) if len(e1) else ""
         if len(e1) and (e1[:, 7] > 0).any():
-            ep += " pass1-again %.2f" % ((e1[:, 7] - e1[:, 6]).mean() / 100.0)
+            ep += " 6->7 %.2f" % ((e1[:, 7] - e1[:, 6]).mean() / 100.0)
+        if "AVAE_STAMPS_PRO" in os.environ.get("EXTRA_DEFS", "") and len(g):
+            ep = "entry->item %.2f  item->addresses %.2f  addresses->loop %.2f" % (
+                (g[:, 6] - g[:, 0]).mean() / 100.0, (g[:, 7] - g[:, 6]).mean() / 100.0, (g[:, 1] - g[:, 7]).mean() / 100.0)
         print("%-16s %6d %8.2f | %7.2f %7.2f %7.2f %7.2f | %8.2f  gap_before=%.2f  %s" % (
             names[l] if l < len(names) else "L%d" % l, live.sum(), span, seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4),
             (t0.max() - t0.min()) / 100.0, gap, ep))

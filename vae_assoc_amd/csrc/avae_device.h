@@ -70,17 +70,21 @@ struct WorkItem {
     float* partial;          // cost partial slots
     const float* eps;        // K_LATENT: the step's eps [B][ldx]
     float wts[kMaxMod];      // K_LATENT: per-modality cost weights
-    // Fused producer (k_fused32, small nets): the A operand of this product is itself a narrow product that used to be a launch of
-    // its own -- forward: A = act(Xs . Ws^T) (the decoder's first layer, K = n_z + 1); dgrad: A = (Xs . Ws^T) * act'(aux) (the head's
-    // input gradient, K = 2 n_z).  Every workgroup recomputes its 32 rows of A into LDS; the workgroups of column tile 0 also store them.
-    const void* pro_x;       // Xs  [rows][pro_ldx]   (z with its constant-1 column, or dH)
-    const void* pro_w;       // Ws  [units][pro_ldw]  (K-contiguous weight shadow of the narrow layer)
-    void* pro_out;           // where A's rows go in HBM (the buffer the separate launch used to write), leading dim lda
-    const void* pro_aux;     // dgrad: stored output of the layer A's gradient belongs to [rows][pro_lda2]
-    int pro_mode;            // 0: none; 1: forward; 2: dgrad
-    int pro_u;               // valid units (columns of A)
-    int pro_ldx, pro_ldw, pro_lda2;
-    int pro_act, pro_ones;   // transfer function; 1: A carries a constant-1 column at index pro_u
+    // Tail product (small nets, 32x64 head tiles): K_FWD_HEAD / K_DGRAD_LATENT items leave a narrow result (z, or [dmu | dlv]) whose
+    // only consumer is a layer that multiplies over one or two K tiles (the decoder's first layer, K = n_z + 1; the heads' input
+    // gradient, K = 2 n_z) and used to be a launch of its own.  With tail_mode set the same workgroup multiplies its 32 result rows, still in
+    // LDS, with that layer's weight shadow (B fragments straight from global memory into registers) and stores the layer's
+    // output: forward  out = act(z_aug . W^T),  dgrad  out = ([dmu|dlv] . W^T) * act'(aux).  The item's tiles_n then counts tail
+    // SLICES of 64 output columns: slice s of a row block is a workgroup of its own that recomputes the 32x64 head tile (cheap: the
+    // slices of a row block share an XCD and its L2) and multiplies columns [64 s, 64 s + 64); slice 0 also stores the head's results.
+    const void* tail_w;      // [tail_n][tail_ldw]: K-contiguous weight shadow of the consuming layer
+    void* tail_out;          // [rows][tail_ldo]
+    const void* tail_aux;    // mode 2: stored output of the layer the gradient belongs to [rows][tail_ldx]
+    int tail_mode;           // 0: none; 1: forward hidden layer; 2: dgrad of a hidden layer
+    int tail_n;              // units of the consuming layer (columns of its output)
+    int tail_ldw, tail_ldo, tail_ldx;
+    int tail_act;
+    int tail_kt;             // K tiles of the consuming layer's product: 1, or 2 (fp32 [dmu | dlv] with n_z > 16)
     // K_LATENT reuses the pointer fields: [mu|lv] inputs of modality 0..3 = A, B, aux0, aux1;
     // static-gradient outputs g0 of modality 0..3 = out0, out1, out2, aux2.
     // K_COST: scale = lr, lambda = beta1, inv_bg = beta2 (it also publishes this step's Adam lr_t).
@@ -306,8 +310,6 @@ constexpr int kStampLaunches = 32, kStampBlocks = 1024, kStampWords = 8;
 
 // launchers implemented in avae_kernels.hip
 int tile_lds_bytes(int tile_cfg, bool two_c_tiles);
-int fused32_lds_bytes(int es, int k_main_elems);          // LDS of k_fused32 for a main product of K (padded) elements
-void launch_fused32(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s);
 void launch_grouped(int compute_dtype, int tile_cfg, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes,
                     DevState* st, hipStream_t s, unsigned long long* stamps = nullptr, int launch_id = 0);
 void launch_grouped_tn(int compute_dtype, int tile_cfg, const TnLaunchArgs& args, int grid_x, int grid_y, int lds_bytes,

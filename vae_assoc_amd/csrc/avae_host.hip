@@ -939,37 +939,43 @@ void build_training_plan(avae_handle* h) {
         if (count <= 0) return;
         dst.push_back(finish_launch(h, h->items, first, count, name, &slot));
     };
-    // Small nets: a launch whose every item multiplies over ONE K tile (the decoder's first layer, the heads' input gradient) is
-    // folded into the launch that consumes its output, when that one runs on 32x32 tiles: its items become the `pro_*` producer of
-    // the consumer's items (k_fused32) and the launch disappears -- 4.3 us each on C2.  `mode` 1: forward, 2: dgrad.
-    auto fuse_into_next = [&](std::vector<Launch>& ls, int mode) {
-        if (ls.size() < 2 || !std::getenv("AVAE_FUSE")) return;   // opt-in: measured slower than the two launches
-        Launch& Ln = ls[ls.size() - 2];          // narrow
-        Launch& Lc = ls[ls.size() - 1];          // consumer
-        if (Ln.type != 0 || Lc.type != 0 || Ln.tn || Lc.tn || Lc.cfg != 5 || Ln.count != Lc.count || Lc.count > kMaxItemsPerLaunch) return;
-        int lds = 0;
+    // Small nets: the launch that follows the heads (the decoder's first layer, K = n_z + 1) and the one that follows bwd_dec1_latent
+    // (the heads' input gradient, K = 2 n_z) multiply over one or two K tiles and are pure launch overhead (4.3 us each on C2).  When the
+    // producing launch runs on 32x64 tiles they become the tail product of its items (WorkItem::tail_*) and disappear.  The weights
+    // they read are final since the previous step's Adam, their inputs exist only in the producing workgroup -- nothing else changes.
+    auto fuse_tail = [&](std::vector<Launch>& ls, int mode) {
+        if (ls.size() < 2 || std::getenv("AVAE_NO_TAIL")) return false;
+        Launch& Lp = ls[ls.size() - 2];          // producer: fwd_head / bwd_dec1_latent
+        Launch& Lc = ls[ls.size() - 1];          // consumer: one K tile
+        if (Lp.type != 0 || Lc.type != 0 || Lp.tn || Lc.tn || Lp.cfg != 3) return false;
+        const int want_p = mode == 1 ? K_FWD_HEAD : K_DGRAD_LATENT, want_c = mode == 1 ? K_FWD_HIDDEN : K_DGRAD_HIDDEN;
+        std::vector<int> prod(Lc.count, -1);
         for (int i = 0; i < Lc.count; ++i) {
-            const WorkItem& n = h->items[Ln.first + i];
             const WorkItem& c = h->items[Lc.first + i];
-            const int want_n = mode == 1 ? K_FWD_HIDDEN : K_DGRAD_HIDDEN;
-            if (n.kind != want_n || c.kind != want_n || c.bias_ep) return;
-            if (n.K != h->KU) return;                                        // one K tile
-            if (c.A != n.out0 || c.lda != n.ld0) return;                     // the consumer's A operand is exactly what the narrow item writes
-            if (c.K < n.N || c.K % h->KU || c.K > 512) return;               // (k_fused32: at most 32 unit tiles of 16)
-            lds = std::max(lds, fused32_lds_bytes(h->es, c.K));
+            if (c.kind != want_c || c.bias_ep || c.K > 2 * h->KU || c.N > 1024) return false;      // (the narrow result is one 64-column tile)
+            for (int k = 0; k < Lp.count; ++k) {
+                const WorkItem& n = h->items[Lp.first + k];
+                if (n.kind != want_p || n.M != c.M) continue;
+                const void* res = mode == 1 ? n.out1 : n.out0;
+                const int ldres = mode == 1 ? n.ld1 : n.ld0;
+                if (res && res == c.A && ldres == c.lda) prod[i] = k;
+            }
+            if (prod[i] < 0) return false;
         }
-        if (lds > 160 * 1024) return;
         for (int i = 0; i < Lc.count; ++i) {
-            const WorkItem n = h->items[Ln.first + i];
-            for (WorkItem* c : {&h->items[Lc.first + i], &Lc.args.items[i]}) {
-                c->pro_mode = mode; c->pro_x = n.A; c->pro_ldx = n.lda; c->pro_w = n.B; c->pro_ldw = n.ldb; c->pro_u = n.N;
-                c->pro_out = n.out0; c->pro_act = n.act; c->pro_aux = n.aux0; c->pro_lda2 = n.ldx;
-                c->pro_ones = mode == 1 ? 1 : 0;                             // forward activations carry the constant-1 (bias) column at index N
+            const WorkItem c = h->items[Lc.first + i];
+            for (WorkItem* n : {&h->items[Lp.first + prod[i]], &Lp.args.items[prod[i]]}) {
+                n->tail_mode = mode; n->tail_w = c.B; n->tail_ldw = c.ldb; n->tail_n = c.N; n->tail_out = c.out0; n->tail_ldo = c.ld0;
+                n->tail_aux = c.aux0; n->tail_ldx = c.ldx; n->tail_act = c.act; n->tail_kt = c.K / h->KU;
+                n->tiles_n = (c.N + 63) / 64;                    // tail slices of 64 columns, a workgroup each
             }
         }
-        Lc.cfg = 8; Lc.lds = lds;
-        Lc.name = Ln.name + "+" + Lc.name;
-        ls.erase(ls.end() - 2);
+        int max_tiles = 1;
+        for (int k = 0; k < Lp.count; ++k) max_tiles = std::max(max_tiles, h->items[Lp.first + k].tiles_m * h->items[Lp.first + k].tiles_n);
+        Lp.grid_x = (max_tiles + 7) & ~7; Lp.blocks = Lp.grid_x * Lp.grid_y; Lp.args.grid_x = Lp.grid_x;
+        Lp.name += "+" + Lc.name;
+        ls.pop_back();
+        return true;
     };
     // conv-branch helper launches (one segment per conv modality)
     // (`want`: which conv modalities take part -- stages route per modality: patch-matrix, adjoint-frame or direct)
@@ -1055,7 +1061,7 @@ void build_training_plan(avae_handle* h) {
         group("fwd_dec" + std::to_string(k + 1), h->fwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k]));
         });
-        if (k == 1 && !any_conv) fuse_into_next(h->fwd, 1);                   // fwd_dec1 -> prologue of fwd_dec2
+        if (k == 0 && !any_conv && !latent_alone && fuse_tail(h->fwd, 1)) h->fwd_dec_first = (int)h->fwd.size() - 1;      // fwd_dec1 rides in fwd_head
     }
     if (any_conv) {   // adjoint filter shadows of the transposed-conv stages that run through Padj / the scatter product (refreshed once per step)
         Launch L;
@@ -1154,6 +1160,7 @@ void build_training_plan(avae_handle* h) {
             else h->items.push_back(bd.dgrad_hidden(md.dH, md.head, md.E.back(), md.dE.back()));
         }
     });
+    if (!any_conv) fuse_tail(h->bwd, 2);                                      // bwd_head rides in bwd_dec1_latent
     if (any_conv) {
         for (int i = 3; i >= 1; --i) {
             col2im_launch("conv_enc" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cenc[i]; },
@@ -1165,7 +1172,6 @@ void build_training_plan(avae_handle* h) {
         group("bwd_enc" + std::to_string(k + 1), h->bwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.dgrad_hidden(md.dE[k], md.enc[k], md.E[k - 1], md.dE[k - 1]));
         });
-        if (k == Lmax - 1 && !any_conv) fuse_into_next(h->bwd, 2);            // bwd_head -> prologue of the last encoder layer's dgrad
     }
     // ---- every weight gradient in the last launch(es) of the step: they depend only on stored activations /
     // activation gradients, and nothing reads the weights after them, so k_adam follows directly (after the all-reduce
@@ -1486,7 +1492,6 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         else if (L.type == 6) launch_wadj(h->cfg.compute_dtype, L.wa, L.blocks, s);
         else if (L.type == 7) launch_gperm(L.gp, L.blocks, s);
         else if (L.type == 8) launch_rowsum(h->cfg.compute_dtype, L.rs, L.blocks, s);
-        else if (L.cfg == 8) launch_fused32(h->cfg.compute_dtype, L.args, L.grid_x, L.grid_y, L.lds, s);
         else if (L.tn) launch_grouped_tn(h->cfg.compute_dtype, L.cfg, L.targs, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         LAUNCH_OK(L.name);
@@ -1602,7 +1607,7 @@ Launch relocated(const avae_handle* h, const Launch& L0, int j) {
     for (int i = 0; i < L.args.n_items && L.type == 0; ++i) {
         WorkItem& w = L.args.items[i];
         fix(w.A); fix(w.B); fix(w.out0); fix(w.out1); fix(w.out2); fix(w.aux0); fix(w.aux1); fix(w.aux2); fix(w.eps);
-        fix(w.pro_x); fix(w.pro_w); fix(w.pro_out); fix(w.pro_aux);
+        fix(w.tail_w); fix(w.tail_out); fix(w.tail_aux);
     }
     for (int i = 0; i < L.targs.n_items && L.type == 0; ++i) { TnItem& t = L.targs.items[i]; fix(t.A); fix(t.B); fix(t.out); }
     for (int i = 0; i < L.ga.n_seg && L.type == 1; ++i) fix(L.ga.seg[i].src);

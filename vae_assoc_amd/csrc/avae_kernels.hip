@@ -538,6 +538,11 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
 #define AVAE_STAMP(i)
 #define AVAE_STAMP_FLUSH()
 #endif
+#ifdef AVAE_STAMPS_PRO       /* words 6 and 7 belong to the prologue stamps in that build */
+#define AVAE_STAMP_EP(i)
+#else
+#define AVAE_STAMP_EP(i) AVAE_STAMP(i)
+#endif
 #if defined(AVAE_STAMPS) && defined(AVAE_LOOPSTAMPS)
     // diagnostic: shader-clock cycles per section of the K loop, summed over the K tiles of this workgroup (wave 0)
     unsigned long long la[6] = {0, 0, 0, 0, 0, 0}, lt = 0;
@@ -574,6 +579,10 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
     // first load of every workgroup.  Naming the fields here puts all their s_loads ahead of the first wait.
     if constexpr (TN) asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.kchunk), "s"(lds_bytes));
     else asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.aux0), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.ldx), "s"(lds_bytes));
+#ifdef AVAE_STAMPS_PRO       /* diagnostic: where the time before the first load goes (6: item descriptor here, 7: addresses set up) */
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AVAE_STAMP(6)
+#endif
     int t;                       // bijective for any tile count; only speed depends on the order
     {
         const int nt = TN ? w.tile_cnt : w.tiles_m * w.tiles_n;
@@ -605,7 +614,13 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int tm = t / w.tiles_n, tn = t - tm * w.tiles_n;
+    // Tail product (WorkItem::tail_*): the item's tiles_n counts tail SLICES, not column tiles -- every slice's workgroup computes
+    // the (single) 32x64 head tile of its row block and then its own 64 columns of the consuming layer.
+    constexpr bool TAIL = !TN && NW == 4 && BM == 32 && BN == 64;
+    bool tail_on = false;
+    if constexpr (TAIL) tail_on = w.tail_mode != 0;
+    const int tm = t / w.tiles_n, tn_raw = t - tm * w.tiles_n;
+    const int tn = tail_on ? 0 : tn_raw, ts = tail_on ? tn_raw : 0;
     const int m0 = tm * BM, n0 = tn * BN;
 
     // NT: the tile's rows are rows of A / B (K contiguous).  TN: its rows are K (batch samples), its columns m0.. / n0..
@@ -659,6 +674,10 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
             kadv[c] = kTileBytesK;
         }
     }
+#ifdef AVAE_STAMPS_PRO
+    asm volatile("" :: "v"(src[0]));
+    AVAE_STAMP(7)
+#endif
     const int sw0 = (fq ^ (fr >> 1)) * 16;                              // swizzled chunk of K-slab 0; slab 1 = ^64
     const int aoff = (wr * WM + fr) * kTileBytesK;
     const int boff = (BM + wc * WN + fr) * kTileBytesK;
@@ -879,6 +898,74 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
 #undef AVAE_WAIT_TILE
     lds_barrier();
     AVAE_STAMP(3)
+    // ---- tail product: wave v of slice ts owns row block (v & 1) and the column-block pair 2 ts + (v >> 1) of the consuming layer,
+    // i.e. 16 rows x 32 columns.  Its B fragments -- weight-shadow rows c0 + 16 j + (lane & 15), 16-byte chunks (lane >> 4) and
+    // (lane >> 4) + 4 -- come straight from global memory into registers, issued here so that they travel while the head's own
+    // epilogue runs; a block past the layer's last unit re-reads its last row (never stored).
+    // column blocks per wave; 64-byte K slabs at most: the narrow result has <= 64 columns = one K tile of bf16, up to two of fp32
+    // (bf16: compile-time 2 slabs, no guards -- the guarded 4-slab code cost the bf16 launches 0.7 us each)
+    constexpr int TJ = 2, TSL = sizeof(CT) == 2 ? 2 : 4;
+    u32x4 tb[TSL][TJ];
+    int t_sl = 0;
+    typename Quad<CT>::raw ty[TJ];
+    const int t_i = wave_u & 1, t_c0 = (2 * ts + (wave_u >> 1)) * 32;
+    if constexpr (TAIL) {
+        if (tail_on) {
+            const unsigned char* wb = reinterpret_cast<const unsigned char*>(w.tail_w);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const unsigned char* pw = wb + (size_t)min(t_c0 + 16 * j + fr, w.tail_n - 1) * w.tail_ldw * ES + fq * 16;
+#pragma unroll
+                for (int sl = 0; sl < TSL; ++sl)
+                    if (TSL == 2 || sl < 2 * w.tail_kt) tb[sl][j] = *reinterpret_cast<const u32x4*>(pw + 64 * sl);
+            }
+            t_sl = 2 * w.tail_kt;
+            if (w.tail_mode == 2) {
+                const CT* Yp = reinterpret_cast<const CT*>(w.tail_aux);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    ty[j] = *reinterpret_cast<const typename Quad<CT>::raw*>(
+                        Yp + (size_t)min(m0 + 16 * t_i + fr, w.M - 1) * w.tail_ldx + min(t_c0 + 16 * j + 4 * fq, w.tail_ldx - 4));
+            }
+        }
+    }
+    // Zt: the narrow result as the kind's epilogue left it in LDS (fp32, cs_idx layout), kcols valid columns; one_col: index of the
+    // constant-1 (bias) column the stored copy carries, -1 for none.  Same rounding points as the stored copy, same K order.
+    auto tail_product = [&](const float* Zt, int kcols, int one_col) __attribute__((always_inline)) {     // (two call sites: must not become a function, its captures would live in scratch)
+        if constexpr (TAIL) {
+            AVAE_STAMP_EP(6)
+            constexpr int EPC = 16 / ES;
+            u32x4 ta[TSL];
+#pragma unroll
+            for (int sl = 0; sl < TSL; ++sl) {
+                float v[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const int d = (fq + 4 * sl) * EPC + e;
+                    v[e] = d < kcols ? Zt[cs_idx<LDC>(16 * t_i + fr, d)] : (d == one_col ? 1.0f : 0.0f);
+                }
+                if constexpr (sizeof(CT) == 2) ta[sl] = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+                else ta[sl] = __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]});
+            }
+            f32x4 tacc[1][TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                tacc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < TSL; ++sl)
+                    if (TSL == 2 || sl < t_sl) mma<CT>(tb[sl][j], ta[sl], tacc[0][j]);       // swapped operands: row on the lane, 4 consecutive units in the registers
+            }
+            AVAE_STAMP_EP(7)
+            CT* To = reinterpret_cast<CT*>(w.tail_out);
+            if (w.tail_mode == 1) {
+                AVAE_ACT_DISPATCH(w.tail_act, (regep_store<CT, 1, TJ>(tacc, To, w.tail_ldo, w.M, w.tail_n, m0 + 16 * t_i + fr, t_c0, lane,
+                    [&](int, int, int, float v) { return act_fwd_t<ACT>(v); })))
+            } else {
+                AVAE_ACT_DISPATCH(w.tail_act, (regep_store<CT, 1, TJ>(tacc, To, w.tail_ldo, w.M, w.tail_n, m0 + 16 * t_i + fr, t_c0, lane,
+                    [&](int, int j, int r, float v) { return v * act_bwd_t<ACT>(quad_elem<CT>(ty[j], r)); })))
+            }
+        }
+    };
 #if defined(AVAE_STAMPS) && defined(AVAE_LOOPSTAMPS)
     for (int i_ = 0; i_ < 6; ++i_) sv[1 + i_] = la[i_];
     sv[7] = (unsigned long long)nk;
@@ -988,7 +1075,7 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
         CT* Y = reinterpret_cast<CT*>(w.out0);
         AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, false, false, BM, BN, NT>(Cs, Y, w.ld0, (const CT*)nullptr, 4, M, N, m0, n0,
             [](float c, float, bool) { return act_fwd_t<ACT>(c); })))
-        AVAE_STAMP(6)
+        AVAE_STAMP_EP(6)
     } break;
     case K_FWD_HEAD: {
       if constexpr (NW == 4) {     // 8-wave tiles carry the plain kinds only (host: finish_launch)
@@ -1024,12 +1111,15 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
                 }
             }
         }
-        tile_pass<float, float, false, false, BM, BN>(Cs, reinterpret_cast<float*>(w.out0), w.ld0, (const float*)nullptr, 4,
-                                                      M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
+        if (ts == 0)             // (tail slices > 0 recompute the head tile for its z only)
+            tile_pass<float, float, false, false, BM, BN>(Cs, reinterpret_cast<float*>(w.out0), w.ld0, (const float*)nullptr, 4,
+                                                          M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
         if (w.out1) {
             lds_barrier();
-            tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out1), w.ld1, (const CT*)nullptr, 8,
-                                                    M, nz, m0, 0, [](float c, float, bool) { return c; });
+            if (ts == 0)
+                tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out1), w.ld1, (const CT*)nullptr, 8,
+                                                        M, nz, m0, 0, [](float c, float, bool) { return c; });
+            if (tail_on) tail_product(Zs, nz, nz);                   // the decoder's first layer on [z | 1]
         }
       }
     } break;
@@ -1125,8 +1215,10 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
             }
         }
         lds_barrier();
-        tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out0), w.ld0, (const CT*)nullptr, 8,
-                                                M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
+        if (ts == 0)
+            tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out0), w.ld0, (const CT*)nullptr, 8,
+                                                    M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
+        if (tail_on) tail_product(Zs, 2 * nz, -1);                   // the heads' input gradient on [dmu | dlv]
       }
     } break;
     case K_DGRAD_F32:
@@ -1226,193 +1318,6 @@ void launch_grouped_tn(int compute_dtype, int tile_cfg, const TnLaunchArgs& args
     else AVAE_GO(float, true);
 }
 #undef AVAE_GO
-
-// ------------------------------------------------------------------ small nets: narrow layer fused into its consumer's prologue
-// C1 / C2 / C3 / C5 run a chain of ~4-us launches whose K loops are a fraction of that; two of them multiply over a single K tile
-// (the decoder's first layer, K = n_z + 1, and the heads' input gradient, K = 2 n_z) and are pure launch overhead.  k_fused32 is
-// the 32x32-tile product (4 waves, 4-stage LDS-DMA ring, k_grouped's NT conventions: 128-byte rows, chunk c of row r at
-// c ^ ((r >> 1) & 7)) whose A operand never comes from HBM: every workgroup first DMAs the narrow layer's input rows (32 x 128 B)
-// and its whole weight shadow (units x 128 B) into LDS, multiplies them (swapped MFMA operands: row on the lane, 4 consecutive
-// units in the registers), applies the transfer function (forward) or act'(stored output) (dgrad) and writes the 32 x K result into
-// LDS in the K-tile image the main loop's A fragments are read from; workgroups of column tile 0 also store it to HBM, where the
-// backward pass and the weight gradients expect it.  The main loop then streams only the B operand.  Bitwise the separate launches'
-// results (same products, same K order, same rounding points).
-int fused32_lds_bytes(int es, int k_main_elems) {
-    const int nk = k_main_elems * es / kTileBytesK;           // K tiles of the main product = 128-byte rows of A per tile row
-    return 4 * 32 * kTileBytesK                               // B ring
-         + 32 * kTileBytesK                                   // Xs
-         + nk * (kTileBytesK / es) * kTileBytesK              // Ws: one 128-byte row per unit, units padded to whole K tiles
-         + nk * 32 * kTileBytesK                              // resident A
-         + 64;
-}
-
-template <typename CT>
-__global__ void __launch_bounds__(kThreads) k_fused32(const LaunchArgs args, int lds_bytes) {
-    constexpr int BM = 32, BN = 32, RING = 4, ES = (int)sizeof(CT), EPR = kTileBytesK / ES, LDC = BN + 4;
-    constexpr int kStageB = BN * kTileBytesK;                 // a ring stage holds the B part only
-    unsigned char* smem = avae_dyn_smem;
-    // item and tile (k_grouped's XCD-aware order)
-    const int part = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const WorkItem w = args.items[blockIdx.y];
-    asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.aux0), "s"(w.pro_x), "s"(w.pro_w), "s"(w.pro_out), "s"(w.K), "s"(w.ldb), "s"(w.ld0));
-    int t;
-    {
-        const int nt = w.tiles_m * w.tiles_n;
-        const int q = nt / 8, r = nt - q * 8;
-        if (idx >= q + (part < r ? 1 : 0)) return;
-        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx;
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
-    const int tm = t / w.tiles_n, tn = t - tm * w.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = (w.K * ES) / kTileBytesK;
-    const int units_p = nk * EPR;                             // units of the narrow layer, padded to whole K tiles
-    unsigned char* Xs = smem + RING * kStageB;
-    unsigned char* Ws = Xs + 32 * kTileBytesK;
-    unsigned char* Ar = Ws + (size_t)units_p * kTileBytesK;
-    typedef const __attribute__((address_space(1))) void* gp_t;
-    typedef __attribute__((address_space(3))) void* lp_t;
-    const int prow = lane >> 3;                               // row of a DMA piece this lane fetches (8 rows x 128 B per piece)
-    // ---- prologue DMAs: Xs (4 pieces), Ws (units_p / 8 pieces), then the first RING-1 B tiles (one piece per wave and tile)
-    {
-        const unsigned char* xg = reinterpret_cast<const unsigned char*>(w.pro_x) + (size_t)m0 * w.pro_ldx * ES;
-        const int r = wave_u * 8 + prow;                      // piece `wave` = rows 8*wave ..
-        const int lc = (lane & 7) ^ ((r >> 1) & 7);
-        __builtin_amdgcn_global_load_lds((gp_t)(xg + (size_t)r * w.pro_ldx * ES + lc * 16), (lp_t)(Xs + wave_u * 1024), 16, 0, 0);
-    }
-    const int n_wp = units_p / 8;                             // pieces of Ws; piece p goes to wave p % 4
-    for (int p = wave_u; p < n_wp; p += 4) {
-        const int r = p * 8 + prow;
-        const int lc = (lane & 7) ^ ((r >> 1) & 7);
-        __builtin_amdgcn_global_load_lds((gp_t)(reinterpret_cast<const unsigned char*>(w.pro_w) + (size_t)r * w.pro_ldw * ES + lc * 16),
-                                         (lp_t)(Ws + p * 1024), 16, 0, 0);
-    }
-    const unsigned char* Bg = reinterpret_cast<const unsigned char*>(w.B) + (size_t)n0 * w.ldb * ES;
-    const unsigned char* bsrc;                                // this wave's piece of a B tile: rows 8*wave ..
-    {
-        const int r = wave_u * 8 + prow;
-        bsrc = Bg + (size_t)r * w.ldb * ES + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
-    }
-#define AVAE_F_DMA(kt, buf) __builtin_amdgcn_global_load_lds((gp_t)(bsrc + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kStageB + wave_u * 1024), 16, 0, 0)
-    const int npro = nk < RING - 1 ? nk : RING - 1;
-    for (int p = 0; p < npro; ++p) AVAE_F_DMA(p, p);
-    // epilogue-side operand of the dgrad producer: stored output of the layer (act'), 4 units per lane and unit tile, in flight meanwhile
-    // ---- the narrow product: wave (wr, wc) owns rows 16 wr .. and the unit tiles g with g % 2 == wc
-    // Xs / Ws have landed once only the B tiles issued behind them are outstanding (<= 3 pieces per wave)
-    if (npro == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (npro == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    const int sw0 = (fq ^ (fr >> 1)) * 16;
-    {
-        const u32x4 a0 = *reinterpret_cast<const u32x4*>(Xs + (wr * 16 + fr) * kTileBytesK + sw0);
-        const u32x4 a1 = *reinterpret_cast<const u32x4*>(Xs + (wr * 16 + fr) * kTileBytesK + (sw0 ^ 64));
-        const int row = wr * 16 + fr;                         // row of the tile this lane holds (swapped operands), units 4 fq ..
-        const int grow = m0 + row;
-        const int n_ut = units_p / 16;
-        const bool store_a = tn == 0 && grow < w.M;
-        // A wave owns at most kMaxG unit tiles (units_p <= 512).  The loops below are fully unrolled and branch-free up to the stores
-        // (a unit tile beyond the wave's last one is the last one computed again), so that all fragment reads -- and, for the
-        // dgrad producer, all 16 loads of the stored activations -- are in flight together instead of one round trip per tile.
-        constexpr int kMaxG = 16;
-        const int g_last = n_ut - 2 + wc;                     // this wave's last unit tile (n_ut is a multiple of 4)
-        typename Quad<CT>::raw yq[kMaxG];
-        if (w.pro_mode == 2) {
-            const CT* ybase = reinterpret_cast<const CT*>(w.pro_aux) + (size_t)min(grow, w.M - 1) * w.pro_lda2;
-#pragma unroll
-            for (int gi = 0; gi < kMaxG; ++gi) {
-                const int g = min(wc + 2 * gi, g_last);
-                yq[gi] = *reinterpret_cast<const typename Quad<CT>::raw*>(ybase + min(g * 16 + 4 * fq, w.pro_lda2 - 4));
-            }
-        }
-        f32x4 pacc[kMaxG];
-#pragma unroll
-        for (int gi = 0; gi < kMaxG; ++gi) {
-            const int g = min(wc + 2 * gi, g_last);
-            const u32x4 b0 = *reinterpret_cast<const u32x4*>(Ws + (g * 16 + fr) * kTileBytesK + sw0);
-            const u32x4 b1 = *reinterpret_cast<const u32x4*>(Ws + (g * 16 + fr) * kTileBytesK + (sw0 ^ 64));
-            pacc[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma<CT>(b0, a0, pacc[gi]);                        // swapped: pacc[gi][r] = A[row][unit0 + r]
-            mma<CT>(b1, a1, pacc[gi]);
-        }
-#pragma unroll
-        for (int gi = 0; gi < kMaxG; ++gi) {
-            const int g = wc + 2 * gi;
-            const int unit0 = min(g, g_last) * 16 + 4 * fq;
-            float v[4];
-            if (w.pro_mode == 2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = unit0 + r < w.pro_u ? pacc[gi][r] * act_bwd(w.pro_act, quad_elem<CT>(yq[gi], r)) : 0.0f;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = unit0 + r < w.pro_u ? act_fwd(w.pro_act, pacc[gi][r]) : ((w.pro_ones && unit0 + r == w.pro_u) ? 1.0f : 0.0f);
-            }
-            if (g <= g_last) {
-                // into the resident A image: K tile kt = unit / EPR, 16-byte chunk (unit % EPR) * ES / 16, swizzled by the row
-                const int kt = unit0 / EPR, ub = (unit0 - kt * EPR) * ES;
-                unsigned char* dst = Ar + (size_t)kt * (32 * kTileBytesK) + row * kTileBytesK + ((((ub >> 4) ^ ((row >> 1) & 7)) << 4) | (ub & 15));
-                if constexpr (sizeof(CT) == 2) {
-                    const bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(dst) = pk;
-                } else {
-                    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                }
-                if (store_a && unit0 < w.pro_u)                // (the constant-1 column of the HBM copy was set at create and is never written)
-                    store_row<CT>(reinterpret_cast<CT*>(w.pro_out) + (size_t)grow * w.lda + unit0, v, w.pro_u - unit0);
-            }
-        }
-    }
-    // ---- main K loop: A fragments from the resident image, B through the ring (one piece per wave and tile)
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int aoff = (wr * 16 + fr) * kTileBytesK, boff = (wc * 16 + fr) * kTileBytesK;
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int rem = nk - 1 - kt, nb = rem < RING - 2 ? rem : RING - 2;
-        if (nb == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (nb == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();                                        // (kt = 0: also orders the A image written above)
-        const unsigned char* Sb = smem + buf * kStageB;
-        const unsigned char* Sa = Ar + (size_t)kt * (32 * kTileBytesK);
-        const u32x4 a0 = *reinterpret_cast<const u32x4*>(Sa + aoff + sw0), b0 = *reinterpret_cast<const u32x4*>(Sb + boff + sw0);
-        const int fill = buf == 0 ? RING - 1 : buf - 1;
-        if (kt + RING - 1 < nk) AVAE_F_DMA(kt + RING - 1, fill);
-        const u32x4 a1 = *reinterpret_cast<const u32x4*>(Sa + aoff + (sw0 ^ 64)), b1 = *reinterpret_cast<const u32x4*>(Sb + boff + (sw0 ^ 64));
-        mma<CT>(a0, b0, acc);
-        mma<CT>(a1, b1, acc);
-        buf = buf + 1 == RING ? 0 : buf + 1;
-    }
-#undef AVAE_F_DMA
-    lds_barrier();
-    // ---- epilogue: k_grouped's LDS-staged passes (the ring is free now)
-    float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Cs[cs_idx<LDC>(wr * 16 + fq * 4 + r, wc * 16 + fr)] = acc[r];
-    lds_barrier();
-    const int M = w.M, N = w.N;
-    if (w.kind == K_FWD_HIDDEN) {
-        CT* Y = reinterpret_cast<CT*>(w.out0);
-        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, false, false, BM, BN>(Cs, Y, w.ld0, (const CT*)nullptr, 4, M, N, m0, n0,
-            [](float c, float, bool) { return act_fwd_t<ACT>(c); })))
-    } else {                 // K_DGRAD_HIDDEN
-        CT* dX = reinterpret_cast<CT*>(w.out0);
-        const CT* Yp = reinterpret_cast<const CT*>(w.aux0);
-        AVAE_ACT_DISPATCH(w.act, (tile_pass<CT, CT, true, false, BM, BN>(Cs, dX, w.ld0, Yp, w.ldx, M, N, m0, n0,
-            [](float c, float y, bool) { return c * act_bwd_t<ACT>(y); })))
-    }
-}
-
-void launch_fused32(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s) {
-    static const bool once = [] {
-        set_max_lds(k_fused32<__bf16>); set_max_lds(k_fused32<float>);
-        return true;
-    }();
-    (void)once;
-    dim3 grid(grid_x, grid_y), block(kThreads);
-    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_fused32<__bf16>), grid, block, lds_bytes, s, args, lds_bytes);
-    else AVAE_LAUNCH((k_fused32<float>), grid, block, lds_bytes, s, args, lds_bytes);
-}
 
 // ------------------------------------------------------------------ Adam + shadow refresh
 // TF-1 AdamOptimizer dense update (reference vae_assoc.py:373-374; TF training_ops ApplyAdam):
