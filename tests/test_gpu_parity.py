@@ -606,11 +606,15 @@ def test_transform_generate_reconstruct_rows(V):
     assert np.abs(model.get_params() - ref.get_params()).max() <= 2e-5
 
 
-def test_generate_serving_buckets(V):
-    """avae_generate (one graph replay per call: slot-indirect staging, grouped decoder launches of every modality, output move):
-    row counts on both sides of the 64-row serving bucket and of batch_size (chunked), interleaved with training steps that use the
-    same activation buffers; fp32 against the oracle, bf16 against the per-modality avae_decode path."""
-    import ctypes as C
+@pytest.mark.parametrize("env", [{}, {"AVAE_NO_TAIL": "1"}])
+def test_generate_serving_buckets(V, monkeypatch, env):
+    """avae_generate (per call: one staging launch that also runs the decoder's first layer as its tail product and publishes the
+    call's slot, then one graph replay of the remaining decoder launches of every modality, whose output launch stores straight into
+    the caller's buffers; AVAE_NO_TAIL=1: plain staging kernel + all decoder launches in the graph): row counts on both sides of the
+    64-row serving bucket and of batch_size (chunked), interleaved with training steps that use the same activation buffers; fp32
+    against the oracle, bf16 bitwise against the per-modality avae_decode path."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
     B = 160
     model, ref = build_pair(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", B, "fp32")

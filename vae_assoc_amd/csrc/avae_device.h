@@ -32,6 +32,10 @@ enum Kind : int {
     K_DGRAD_F32 = 10,    // dP = dA . W^T stored as fp32 (conv branch: patch gradients, summed by k_col2im)
     K_LATENT = 7,        // KL(q||N(0,I)) + association penalty: cost partials + static (mu,lv) grads (:335-366)
     K_COST = 8,          // fixed-order sum of the cost partials -> grad[cost slot]; bumps the step counter
+    K_SERVE_Z = 11,      // serving (avae_generate): no product of its own (K = 0) -- the call's fp32 z rows (aux0, n_slots rows, dense
+                         // [rows][nz]) go into the 32x64 tile's LDS image and the tail product (tail_*) is the decoder's first
+                         // layer; workgroup 0 publishes the call's slot (partial = ServeSlot*, out0/out1/out2/aux1 = the call's
+                         // output pointers of modality 0..3).  Launched per call with these fields patched by value.
 };
 
 struct WorkItem {
@@ -278,24 +282,21 @@ struct RowsumSeg { const void* src; float* part; int ld, rows, cols, cols4, cpow
 struct RowsumArgs { RowsumSeg seg[2 * kMaxMod]; int n_seg; };
 void launch_rowsum(int compute_dtype, const RowsumArgs& a, int n_blocks, hipStream_t s);
 
-// Serving (avae_generate): the captured decode graph reads the caller's pointers and row count from this device-side slot (written
-// by one small hipMemcpyAsync per call), so that one graph serves every call without re-parameterising its nodes.
+// Serving (avae_generate): the captured decode graph's output launch reads the caller's pointers and row count from this
+// device-side slot (written by the per-call staging launch), so that one graph serves every call without re-parameterising its nodes.
 struct ServeSlot {
     const float* z;                // [rows][n_z] fp32, dense
     float* out[kMaxMod];           // per modality [rows][n_input] fp32, dense
     int rows;
     int pad;
 };
-struct ServeArgs {
-    const ServeSlot* slot;
-    int n_mod, nz, bucket;         // rows of the captured plan (>= slot->rows)
+struct ServeArgs {               // the per-call staging launch: z -> Z of every modality (rows beyond the call's rows zero)
+    ServeSlot* slot;
+    int n_mod, nz, bucket;         // rows of the captured plan (>= the call's rows)
     void* Z[kMaxMod]; int ldz[kMaxMod];            // decoder inputs, compute dtype, [bucket][ldz]
-    const float* O[kMaxMod]; int ldo[kMaxMod]; int n_in[kMaxMod];   // decoder outputs (fp32 staging of the store kind)
-    int mode;                      // 0: z -> Z of every modality (rows beyond slot->rows zero);  1: O -> out rows
     int blocks_per_mod;
 };
-void launch_serve(int compute_dtype, const ServeArgs& a, int n_blocks, hipStream_t s);
-void launch_set_slot(ServeSlot* dst, const ServeSlot& v, hipStream_t s);
+void launch_serve(int compute_dtype, const ServeArgs& a, const ServeSlot& call, int n_blocks, hipStream_t s);
 
 void launch_gather(int compute_dtype, const GatherArgs& a, int n_blocks, hipStream_t s);
 void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStream_t s);

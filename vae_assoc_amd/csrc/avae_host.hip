@@ -209,9 +209,10 @@ struct avae_handle {
     // inference tables: per modality, device slots at off_inf
     struct Inf { std::vector<WorkItem> items; std::vector<Launch> launches; int rows = -1; size_t dev_off = 0; };
     std::vector<Inf> inf_enc, inf_dec;
-    // serving (avae_generate): per row bucket one captured graph of [slot-indirect z staging, grouped decoder launches of all
+    // serving (avae_generate): per row bucket one staging launch per call + one captured graph of [grouped decoder launches of all
     // modalities, slot-indirect output move]
-    struct Serve { int bucket = 0; std::vector<WorkItem> items; std::vector<Launch> launches; hipGraphExec_t graph = nullptr; };
+    struct Serve { int bucket = 0; std::vector<WorkItem> items; std::vector<Launch> launches; hipGraphExec_t graph = nullptr; ServeArgs in;
+                   Launch in_launch; bool fused_in = false; };
     std::vector<Serve> serve;
     size_t off_slot = 0;
 
@@ -742,7 +743,7 @@ struct Builder {
     }
 };
 
-inline bool is_gemm(int kind) { return kind <= K_WGRAD || kind == K_DGRAD_F32; }
+inline bool is_gemm(int kind) { return kind <= K_WGRAD || kind == K_DGRAD_F32 || kind == K_SERVE_Z; }
 
 // Fixes the tile configuration of one launch and lays its items' tiles out back to back.
 Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, int count, const std::string& name, int* next_slot) {
@@ -779,7 +780,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         }
         if (nt && t64 > 0 && t64 <= 128) L.cfg = 3;
         bool head = false;
-        for (int i = first; i < first + count; ++i) head = head || items[i].kind == K_FWD_HEAD || items[i].kind == K_DGRAD_LATENT;
+        for (int i = first; i < first + count; ++i) head = head || items[i].kind == K_FWD_HEAD || items[i].kind == K_DGRAD_LATENT || items[i].kind == K_SERVE_Z;
         if (L.cfg == 3 && !head && !std::getenv("AVAE_NO_32x32")) L.cfg = 5;      // no kind that needs 2*n_z columns in one tile
     }
     if (L.cfg == 1 && need128 && !std::getenv("AVAE_NO_64x128")) {      // wide-latent head launches: few tiles, K loop = load latency
@@ -834,7 +835,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
     L.blocks = L.grid_x * L.grid_y;
     {
         bool two = false;
-        for (int i = first; i < first + count; ++i) two = two || items[i].kind == K_FWD_HEAD || items[i].kind == K_DGRAD_LATENT;
+        for (int i = first; i < first + count; ++i) two = two || items[i].kind == K_FWD_HEAD || items[i].kind == K_DGRAD_LATENT || items[i].kind == K_SERVE_Z;
         L.lds = tile_lds_bytes(L.cfg, two);
     }
     L.tn = true;
@@ -1953,24 +1954,46 @@ avae_handle::Serve& serve_plan(avae_handle* h, int bucket) {
         const int count = (int)sv.items.size() - first;
         if (count > 0) sv.launches.push_back(finish_launch(h, sv.items, first, count, name, &slot));
     };
-    for (int k = 0; k < Lmax; ++k)
+    // The decoder's first layer (K = n_z + 1) rides in the per-call staging launch when that fits its tail product (K_SERVE_Z: one K
+    // tile of bf16, two of fp32, at most 1024 units, 32-row tiles); otherwise it is the graph's first launch behind k_serve.
+    {
+        const int first = (int)sv.items.size();
+        bool fits = !std::getenv("AVAE_NO_TAIL") && bucket <= 4096;
+        for (Mod& md : h->mods) {
+            const WorkItem c = bd.fwd_hidden(md.Z, md.dec[0], md.D[0]);
+            fits = fits && c.K <= (h->es == 2 ? 1 : 2) * h->KU && c.N <= 1024 && h->nz + 1 <= 64;
+            WorkItem w = gemm_item(K_SERVE_Z, bucket, c.N, 0, nullptr, 0, nullptr, 0);
+            w.nz = h->nz; w.partial = reinterpret_cast<float*>(h->at<ServeSlot>(h->off_slot));
+            w.tail_mode = 1; w.tail_w = c.B; w.tail_ldw = c.ldb; w.tail_n = c.N; w.tail_out = c.out0; w.tail_ldo = c.ld0; w.tail_act = c.act;
+            w.tail_kt = c.K / h->KU;
+            sv.items.push_back(w);
+        }
+        if (fits) {
+            sv.in_launch = finish_launch(h, sv.items, first, (int)sv.items.size() - first, "serve_in+serve_dec1", &slot);
+            if (sv.in_launch.cfg != 3) fits = false;
+        }
+        if (!fits) sv.items.resize(first);
+        sv.fused_in = fits;
+    }
+    for (int k = sv.fused_in ? 1 : 0; k < Lmax; ++k)
         group("serve_dec" + std::to_string(k + 1), [&] { for (Mod& md : h->mods) if (k < md.L) sv.items.push_back(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k])); });
-    group("serve_out", [&] { for (int m = 0; m < h->M; ++m) sv.items.push_back(bd.fwd_out(h->mods[m], m, false)); });
+    group("serve_out", [&] {
+        for (int m = 0; m < h->M; ++m) {
+            WorkItem w = bd.fwd_out(h->mods[m], m, false);
+            w.aux2 = h->at<void>(h->off_slot); w.n_mod = m;       // K_FWD_OUT_STORE: rows and destination come from the slot
+            sv.items.push_back(w);
+        }
+    });
     ServeArgs a;
     std::memset(&a, 0, sizeof(a));
     a.slot = h->at<ServeSlot>(h->off_slot); a.n_mod = h->M; a.nz = h->nz; a.bucket = bucket;
     for (int m = 0; m < h->M; ++m) {
         const Mod& md = h->mods[m];
         a.Z[m] = h->at<void>(md.Z.rm); a.ldz[m] = md.Z.ld;
-        a.O[m] = h->at<float>(md.out32); a.ldo[m] = md.ld32; a.n_in[m] = md.n_in;
     }
-    auto body = [&](hipStream_t cs) {
-        ServeArgs in = a; in.mode = 0; in.blocks_per_mod = std::max(1, std::min(8, (bucket * h->nz + kThreads - 1) / kThreads));
-        launch_serve(h->cfg.compute_dtype, in, in.blocks_per_mod * h->M, cs); LAUNCH_OK("serve_in");
-        run_launches(h, sv.launches, cs);
-        ServeArgs out = a; out.mode = 1; out.blocks_per_mod = std::max(1, std::min(64, bucket / 4));
-        launch_serve(h->cfg.compute_dtype, out, out.blocks_per_mod * h->M, cs); LAUNCH_OK("serve_out_move");
-    };
+    a.blocks_per_mod = std::max(1, std::min(8, (bucket * h->nz + kThreads - 1) / kThreads));
+    sv.in = a;                                                   // the per-call staging launch (ahead of the graph)
+    auto body = [&](hipStream_t cs) { run_launches(h, sv.launches, cs); };
     const bool tsave = h->timing;
     h->timing = false;
     sv.graph = capture(h, body);
@@ -2399,7 +2422,17 @@ int avae_generate(avae_handle* h, const float* z_dev, int32_t rows, float* const
             std::memset(&sl, 0, sizeof(sl));
             sl.z = z_dev + (size_t)r0 * h->nz; sl.rows = n;
             for (int m = 0; m < h->M; ++m) sl.out[m] = xhat_dev[m] + (size_t)r0 * h->mods[m].n_in;
-            launch_set_slot(h->at<ServeSlot>(h->off_slot), sl, s); LAUNCH_OK("serve_slot");
+            if (sv.fused_in) {           // the staging launch also runs the decoder's first layer: its items carry the call by value
+                Launch& L = sv.in_launch;
+                for (int m = 0; m < h->M; ++m) {
+                    WorkItem& w = L.args.items[m];
+                    w.aux0 = sl.z; w.n_slots = sl.rows;
+                    w.out0 = sl.out[0]; w.out1 = sl.out[1]; w.out2 = sl.out[2]; w.aux1 = sl.out[3];
+                }
+                launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, nullptr, 0); LAUNCH_OK("serve_in+serve_dec1");
+            } else {
+                launch_serve(h->cfg.compute_dtype, sv.in, sl, sv.in.blocks_per_mod * h->M, s); LAUNCH_OK("serve_in");
+            }
             HIP_OK(hipGraphLaunch(sv.graph, s));
         }
     });

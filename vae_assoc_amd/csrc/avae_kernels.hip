@@ -931,7 +931,7 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
     }
     // Zt: the narrow result as the kind's epilogue left it in LDS (fp32, cs_idx layout), kcols valid columns; one_col: index of the
     // constant-1 (bias) column the stored copy carries, -1 for none.  Same rounding points as the stored copy, same K order.
-    auto tail_product = [&](const float* Zt, int kcols, int one_col) __attribute__((always_inline)) {     // (two call sites: must not become a function, its captures would live in scratch)
+    auto tail_product = [&](const float* Zt, int kcols, int one_col) __attribute__((always_inline)) {     // (three call sites: must not become a function, its captures would live in scratch)
         if constexpr (TAIL) {
             AVAE_STAMP_EP(6)
             constexpr int EPC = 16 / ES;
@@ -1155,6 +1155,19 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
     } break;
     case K_FWD_OUT_STORE: {
       if constexpr (NW == 4) {     // 8-wave tiles carry the plain kinds only (host: finish_launch)
+        if (w.aux2) {            // serving (avae_generate): straight into the caller's dense [rows][N] of modality n_mod, through the slot
+            const ServeSlot* sp = reinterpret_cast<const ServeSlot*>(w.aux2);
+            float* dst = sp->out[w.n_mod];
+            const int rows = sp->rows;
+            for (int i = tid; i < BM * BN; i += NT) {
+                const int r = i / BN, c = i - r * BN;
+                if (m0 + r < rows && n0 + c < N) {
+                    const float a = Cs[cs_idx<LDC>(r, c)];
+                    dst[(size_t)(m0 + r) * N + n0 + c] = w.binary ? sigmoidf_(a) : a;
+                }
+            }
+            break;
+        }
         float* O = reinterpret_cast<float*>(w.out0);
         if (w.binary)
             tile_pass<float, float, false, false, BM, BN>(Cs, O, w.ld0, (const float*)nullptr, 4, M, N, m0, n0,
@@ -1219,6 +1232,25 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
             tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out0), w.ld0, (const CT*)nullptr, 8,
                                                     M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
         if (tail_on) tail_product(Zs, 2 * nz, -1);                   // the heads' input gradient on [dmu | dlv]
+      }
+    } break;
+    case K_SERVE_Z: {
+      if constexpr (TAIL) {
+        const int nz = w.nz, rows = w.n_slots;
+        float* Zs = Cs + BM * LDC;
+        const float* zsrc = reinterpret_cast<const float*>(w.aux0);
+        for (int i = tid; i < BM * nz; i += NT) {
+            const int r = i / nz, d = i - r * nz;
+            Zs[cs_idx<LDC>(r, d)] = m0 + r < rows ? zsrc[(size_t)(m0 + r) * nz + d] : 0.0f;
+        }
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+            ServeSlot* sp = reinterpret_cast<ServeSlot*>(w.partial);
+            sp->z = zsrc; sp->rows = rows;
+            sp->out[0] = reinterpret_cast<float*>(w.out0); sp->out[1] = reinterpret_cast<float*>(w.out1);
+            sp->out[2] = reinterpret_cast<float*>(w.out2); sp->out[3] = reinterpret_cast<float*>(const_cast<void*>(w.aux1));
+        }
+        lds_barrier();
+        if (tail_on) tail_product(Zs, nz, nz);                       // the decoder's first layer on [z | 1]
       }
     } break;
     case K_DGRAD_F32:
@@ -1957,38 +1989,25 @@ void launch_thin(int compute_dtype, const ThinArgs& a, int n_blocks, hipStream_t
 }
 
 // ------------------------------------------------------------------ serving: slot-indirect input / output moves
+// Launched per call, ahead of the captured graph, with the call's pointers and row count BY VALUE: it stages z and publishes the
+// slot the graph's output-store launch reads (one launch instead of a slot write + an in-graph staging kernel; the decoder's
+// results go from the output launch's tile straight to the caller's buffers).
 template <typename CT>
-__global__ void __launch_bounds__(kThreads) k_serve(ServeArgs a) {
-    const ServeSlot sl = *a.slot;
+__global__ void __launch_bounds__(kThreads) k_serve(ServeArgs a, ServeSlot call) {
     const int m = blockIdx.x / a.blocks_per_mod, b = blockIdx.x - m * a.blocks_per_mod;
-    if (a.mode == 0) {         // z rows -> Z[m] (compute dtype); padded rows of the bucket are written as zeros
-        const int total = a.bucket * a.nz;
-        for (int i = b * kThreads + threadIdx.x; i < total; i += a.blocks_per_mod * kThreads) {
-            const int r = i / a.nz, c = i - r * a.nz;
-            const float v = r < sl.rows ? sl.z[(size_t)r * a.nz + c] : 0.0f;
-            reinterpret_cast<CT*>(a.Z[m])[(size_t)r * a.ldz[m] + c] = to_ct<CT>(v);
-        }
-    } else {                   // decoder outputs -> the caller's dense [rows][n_input]
-        const int n4 = (a.n_in[m] + 3) >> 2, total = sl.rows * n4;
-        float* dst = sl.out[m];
-        for (int i = b * kThreads + threadIdx.x; i < total; i += a.blocks_per_mod * kThreads) {
-            const int r = i / n4, c = (i - r * n4) * 4;
-            float v[4];
-            load4<float>(a.O[m] + (size_t)r * a.ldo[m] + c, v);     // ldo % 8 == 0: in-row, aligned
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (c + e < a.n_in[m]) dst[(size_t)r * a.n_in[m] + c + e] = v[e];
-        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.slot = call;
+    // z rows -> Z[m] (compute dtype); padded rows of the bucket are written as zeros
+    const int total = a.bucket * a.nz;
+    for (int i = b * kThreads + threadIdx.x; i < total; i += a.blocks_per_mod * kThreads) {
+        const int r = i / a.nz, c = i - r * a.nz;
+        const float v = r < call.rows ? call.z[(size_t)r * a.nz + c] : 0.0f;
+        reinterpret_cast<CT*>(a.Z[m])[(size_t)r * a.ldz[m] + c] = to_ct<CT>(v);
     }
 }
-// the call's pointers and row count, by value -> the device slot the captured graph reads (a one-wave kernel: an H2D copy of 48
-// bytes goes through the copy engine and its stream hand-over, 28 -> 2x us per call measured on avae_generate)
-__global__ void k_set_slot(ServeSlot* dst, ServeSlot v) { if (threadIdx.x == 0) *dst = v; }
-void launch_set_slot(ServeSlot* dst, const ServeSlot& v, hipStream_t s) { AVAE_LAUNCH(k_set_slot, dim3(1), dim3(64), 0, s, dst, v); }
-
-void launch_serve(int compute_dtype, const ServeArgs& a, int n_blocks, hipStream_t s) {
+void launch_serve(int compute_dtype, const ServeArgs& a, const ServeSlot& call, int n_blocks, hipStream_t s) {
     if (n_blocks <= 0) return;
-    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_serve<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
-    else AVAE_LAUNCH((k_serve<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_serve<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a, call);
+    else AVAE_LAUNCH((k_serve<float>), dim3(n_blocks), dim3(kThreads), 0, s, a, call);
 }
 
 // ------------------------------------------------------------------ split-K reduction
