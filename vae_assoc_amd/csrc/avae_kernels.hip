@@ -931,7 +931,9 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
     }
     // Zt: the narrow result as the kind's epilogue left it in LDS (fp32, cs_idx layout), kcols valid columns; one_col: index of the
     // constant-1 (bias) column the stored copy carries, -1 for none.  Same rounding points as the stored copy, same K order.
-    auto tail_product = [&](const float* Zt, int kcols, int one_col) __attribute__((always_inline)) {     // (three call sites: must not become a function, its captures would live in scratch)
+    const float* t_src = nullptr;            // set by the kinds that leave a narrow result for the tail: the LDS image, its valid columns, its constant-1 column
+    int t_cols = 0, t_one = -1;
+    auto tail_product = [&](const float* Zt, int kcols, int one_col) __attribute__((always_inline)) {     // (must not become a function: its captures would live in scratch)
         if constexpr (TAIL) {
             AVAE_STAMP_EP(6)
             constexpr int EPC = 16 / ES;
@@ -1119,7 +1121,7 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
             if (ts == 0)
                 tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out1), w.ld1, (const CT*)nullptr, 8,
                                                         M, nz, m0, 0, [](float c, float, bool) { return c; });
-            if (tail_on) tail_product(Zs, nz, nz);                   // the decoder's first layer on [z | 1]
+            if (tail_on) { t_src = Zs; t_cols = nz; t_one = nz; }     // the decoder's first layer on [z | 1]
         }
       }
     } break;
@@ -1231,7 +1233,7 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
         if (ts == 0)
             tile_pass<CT, CT, false, false, BM, BN>(Zs, reinterpret_cast<CT*>(w.out0), w.ld0, (const CT*)nullptr, 8,
                                                     M, 2 * nz, m0, 0, [](float c, float, bool) { return c; });
-        if (tail_on) tail_product(Zs, 2 * nz, -1);                   // the heads' input gradient on [dmu | dlv]
+        if (tail_on) { t_src = Zs; t_cols = 2 * nz; t_one = -1; }    // the heads' input gradient on [dmu | dlv]
       }
     } break;
     case K_SERVE_Z: {
@@ -1250,7 +1252,7 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
             sp->out[2] = reinterpret_cast<float*>(w.out2); sp->out[3] = reinterpret_cast<float*>(const_cast<void*>(w.aux1));
         }
         lds_barrier();
-        if (tail_on) tail_product(Zs, nz, nz);                       // the decoder's first layer on [z | 1]
+        if (tail_on) { t_src = Zs; t_cols = nz; t_one = nz; }        // the decoder's first layer on [z | 1]
       }
     } break;
     case K_DGRAD_F32:
@@ -1261,6 +1263,7 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
     } break;
     default: break;
     }
+    if (t_src) tail_product(t_src, t_cols, t_one);                   // (the one call site: see tail_product)
     AVAE_STAMP(4)
     AVAE_STAMP_FLUSH()
     return;

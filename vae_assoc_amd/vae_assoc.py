@@ -183,6 +183,17 @@ class AssocVariationalAutoEncoder(object):
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
 
         L = _capi.lib()
+        agree_dev = self.device if (self._sync is not None and self._sync.backend == "nccl") else "cpu"
+        if self._comm_lib and world > 1:
+            # ncclCommInitRank below is collective: a rank that cannot even load RCCL would leave the others waiting inside it.  Every
+            # rank therefore probes the loader first (drawing an id is the cheapest call that needs it) and the ranks agree: all, or
+            # the torch.distributed collective on the same buckets for everybody.
+            probe = (C.c_uint8 * 128)()
+            ok = 1.0 if L.avae_comm_unique_id(probe) == 0 else 0.0
+            if self._sync.sum_scalar(ok, agree_dev) < world:
+                if rank == 0:
+                    print("[vae_assoc_amd] RCCL cannot be loaded on every rank: gradient all-reduce through torch.distributed")
+                self._comm_lib = False
         if self._comm_lib:
             # bootstrap only: rank 0 draws the ncclUniqueId, torch.distributed hands it round; the communicator itself is the library's
             idb = (C.c_uint8 * 128)()
@@ -211,7 +222,20 @@ class AssocVariationalAutoEncoder(object):
         self._cfg = cfg
         h = C.c_void_p()
         torch.cuda.synchronize(self.device)
-        _capi.check(None, L.avae_create(C.byref(cfg), C.byref(h)), "avae_create")
+        rc = L.avae_create(C.byref(cfg), C.byref(h))
+        if self._comm_lib and world > 1:
+            # a communicator that came up on some ranks only is of no use to any: agree, and fall back together
+            if self._sync.sum_scalar(1.0 if rc == 0 else 0.0, agree_dev) < world:
+                if rc == 0:
+                    L.avae_destroy(h)
+                if rank == 0:
+                    print("[vae_assoc_amd] the library's RCCL communicator did not come up on every rank: gradient all-reduce "
+                          "through torch.distributed")
+                self._comm_lib = False
+                cfg.use_comm = 0
+                h = C.c_void_p()
+                rc = L.avae_create(C.byref(cfg), C.byref(h))
+        _capi.check(None, rc, "avae_create")
         self._h = h
         self._L = L
         n = C.c_size_t(0)
