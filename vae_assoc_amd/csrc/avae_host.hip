@@ -1174,6 +1174,103 @@ void build_training_plan(avae_handle* h) {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.dgrad_hidden(md.dE[k], md.enc[k], md.E[k - 1], md.dE[k - 1]));
         });
     }
+    // ---- mixed models: the MLP modalities' hidden-layer launches (a few tiles, 4-5 us each as launches of their own) ride in plain
+    // GEMM launches of the conv modality.  Taken from the end of each chain backwards, a launch sinks into the LATEST such launch
+    // that still runs before the first reader of its outputs -- so a chain enc1 -> enc2 ends up in two consecutive conv launches.
+    // Safe: every buffer is written once per step, so a product may run any time between its inputs' writers and its readers.
+    if (any_conv && !std::getenv("AVAE_NO_SINK")) {
+        auto plain_kind = [](int k) { return k == K_FWD_HIDDEN || k == K_DGRAD_HIDDEN || k == K_DGRAD_F32; };
+        auto reads = [&](const Launch& L, const std::vector<const void*>& outs) {
+            if (L.type != 0) return false;                  // the conv helper launches touch the conv modality's buffers only
+            for (int i = 0; i < L.count; ++i) {
+                const WorkItem& w = h->items[L.first + i];
+                for (const void* q : {w.A, w.B, w.aux0, w.aux1, w.aux2, (const void*)w.tail_w, (const void*)w.tail_aux})
+                    for (const void* o : outs) if (q && q == o) return true;
+            }
+            return false;
+        };
+        auto sink = [&](std::vector<Launch>& ls, int* index_a, int* index_b) {
+            for (int a = (int)ls.size() - 1; a >= 0; --a) {
+                Launch& P = ls[a];
+                if (P.type != 0 || P.tn || P.name.compare(0, 5, "conv_") == 0 || P.name.find('+') != std::string::npos) continue;
+                bool movable = true;
+                std::vector<const void*> outs;
+                for (int i = 0; i < P.count; ++i) {
+                    const WorkItem& w = h->items[P.first + i];
+                    movable = movable && (w.kind == K_FWD_HIDDEN || w.kind == K_DGRAD_HIDDEN) && !w.bias_ep;
+                    outs.push_back(w.out0);
+                }
+                if (!movable) continue;
+                int target = -1;
+                for (int q = a + 1; q < (int)ls.size(); ++q) {
+                    const Launch& Q = ls[q];
+                    if (reads(Q, outs)) break;
+                    bool ok = Q.type == 0 && !Q.tn && Q.name.compare(0, 5, "conv_") == 0 && Q.count + P.count <= kMaxItemsPerLaunch && Q.cfg != 2 && Q.cfg != 6;
+                    for (int i = 0; ok && i < Q.count; ++i) ok = plain_kind(h->items[Q.first + i].kind);
+                    if (ok) target = q;
+                }
+                if (target < 0) continue;
+                Launch& Q = ls[target];
+                const int first = (int)h->items.size();
+                for (int i = 0; i < Q.count; ++i) { const WorkItem w = h->items[Q.first + i]; h->items.push_back(w); }
+                for (int i = 0; i < P.count; ++i) { const WorkItem w = h->items[P.first + i]; h->items.push_back(w); }
+                int dummy_slot = 0;                          // (no kind in here owns cost-partial slots)
+                Launch merged = finish_launch(h, h->items, first, Q.count + P.count, Q.name + "+" + P.name, &dummy_slot);
+                ls[target] = merged;
+                ls.erase(ls.begin() + a);
+                for (int* ix : {index_a, index_b}) if (ix && a < *ix) --*ix;
+            }
+        };
+        // ... and where no such launch lies between a launch and its reader (the backward pass: the MLP modality's dgrad layers come
+        // after the conv decoder's), it is HOISTED into the earliest one behind the writer of its input gradient.
+        auto writes = [&](const Launch& L, const std::vector<const void*>& ins) {
+            if (L.type != 0) return false;
+            for (int i = 0; i < L.count; ++i) {
+                const WorkItem& w = h->items[L.first + i];
+                for (const void* q : {(const void*)w.out0, (const void*)w.out1, (const void*)w.tail_out})
+                    for (const void* o : ins) if (q && q == o) return true;
+            }
+            return false;
+        };
+        auto hoist = [&](std::vector<Launch>& ls, int* index_a) {
+            for (int a = 0; a < (int)ls.size(); ++a) {
+                Launch& P = ls[a];
+                if (P.type != 0 || P.tn || P.name.compare(0, 5, "conv_") == 0 || P.name.find('+') != std::string::npos) continue;
+                bool movable = true;
+                std::vector<const void*> ins;
+                for (int i = 0; i < P.count; ++i) {
+                    const WorkItem& w = h->items[P.first + i];
+                    movable = movable && (w.kind == K_FWD_HIDDEN || w.kind == K_DGRAD_HIDDEN) && !w.bias_ep;
+                    ins.push_back(w.A);
+                }
+                if (!movable) continue;
+                int writer = -1;
+                for (int q = 0; q < a; ++q) if (writes(ls[q], ins)) writer = q;
+                if (writer < 0) continue;                    // (its input comes from the other list: leave it where the plan put it)
+                int target = -1;
+                for (int q = writer + 1; q < a && target < 0; ++q) {
+                    const Launch& Q = ls[q];
+                    bool ok = Q.type == 0 && !Q.tn && Q.name.compare(0, 5, "conv_") == 0 && Q.count + P.count <= kMaxItemsPerLaunch && Q.cfg != 2 && Q.cfg != 6;
+                    for (int i = 0; ok && i < Q.count; ++i) ok = plain_kind(h->items[Q.first + i].kind);
+                    if (ok) target = q;
+                }
+                if (target < 0) continue;
+                Launch& Q = ls[target];
+                const int first = (int)h->items.size();
+                for (int i = 0; i < Q.count; ++i) { const WorkItem w = h->items[Q.first + i]; h->items.push_back(w); }
+                for (int i = 0; i < P.count; ++i) { const WorkItem w = h->items[P.first + i]; h->items.push_back(w); }
+                int dummy_slot = 0;
+                Launch merged = finish_launch(h, h->items, first, Q.count + P.count, Q.name + "+" + P.name, &dummy_slot);
+                ls[target] = merged;
+                ls.erase(ls.begin() + a);
+                if (index_a && a < *index_a) --*index_a;
+                --a;
+            }
+        };
+        sink(h->fwd, &h->fwd_dec_first, nullptr);
+        sink(h->bwd, &h->bwd_split, nullptr);
+        hoist(h->bwd, &h->bwd_split);
+    }
     // ---- every weight gradient in the last launch(es) of the step: they depend only on stored activations /
     // activation gradients, and nothing reads the weights after them, so k_adam follows directly (after the all-reduce
     // under data parallelism).  Fusing Adam into these epilogues was measured and dropped: equal on the small nets
