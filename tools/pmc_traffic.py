@@ -44,8 +44,12 @@ write = per_position("WRITE_SIZE", "write")
 L = len(archs[0]["n_hidden"])
 cd = lambda a, b: -(-a // b)
 latent_alone = (sum(cd(B, 256) * cd(na["n_input"], 64) for na in archs) >= 192 and sum(cd(B, 128) * cd(na["n_input"], 128) for na in archs) >= 192)
-names = (["fwd_enc%d" % (k + 1) for k in range(L)] + ["fwd_head"] + (["latent"] if latent_alone else []) + ["fwd_dec%d" % (k + 1) for k in range(L)] + ["fwd_out_loss", "bwd_out"]
-         + ["bwd_dec%d" % (k + 1) for k in range(L - 1, 0, -1)] + ["bwd_dec1_latent", "bwd_head"]
+import os
+# small nets: fwd_dec1 and bwd_head ride in the launch that produces their input (avae_host.hip::fuse_tail; AVAE_NO_TAIL=1 keeps them apart)
+tail = not latent_alone and not os.environ.get("AVAE_NO_TAIL")
+names = (["fwd_enc%d" % (k + 1) for k in range(L)] + (["fwd_head+fwd_dec1"] if tail else ["fwd_head"]) + (["latent"] if latent_alone else [])
+         + ["fwd_dec%d" % (k + 1) for k in range(1 if tail else 0, L)] + ["fwd_out_loss", "bwd_out"]
+         + ["bwd_dec%d" % (k + 1) for k in range(L - 1, 0, -1)] + (["bwd_dec1_latent+bwd_head"] if tail else ["bwd_dec1_latent", "bwd_head"])
          + ["bwd_enc%d" % (k + 1) for k in range(L - 1, 0, -1)])
 n_wg = len([k for k in fetch if k != "prep"]) - len(names) - 1            # the step ends with k_adam
 names += (["wgrad"] if n_wg == 1 else ["wgrad%d" % (i + 1) for i in range(n_wg)]) + ["adam"]
