@@ -167,9 +167,11 @@ int avae_encode(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld, int
 int avae_decode(avae_handle* h, int32_t m, const float* z_dev, int32_t rows, float* xhat_dev, void* stream);
 /* generate() as the reference's callers use it -- every modality's decoder on the same z (vae_assoc.py:405-419 loops over the
  * modalities; baxter_vae_assoc_writer.py:141-147,259-304 and vae_assoc_model_viewer.py:107-113 call it 10-50 times per search
- * iteration with one live row): ONE submission per call.  xhat_dev[m] = device [rows, n_input_m] float32, dense.  For 1..64
- * rows (and for chunks of batch_size rows) the call is one small host-to-device copy of the pointers + one replay of a captured
- * graph [staging, grouped decoder launches of all modalities, output move]; conv decoders go through avae_decode's path. */
+ * iteration with one live row).  xhat_dev[m] = device [rows, n_input_m] float32, dense.  For 1..64 rows (and for chunks of
+ * batch_size rows) the call is one launch that carries the call's pointers by value (it stages z, runs the decoder's first layer of
+ * every modality and publishes the pointers to the device) + one replay of a captured graph [remaining decoder launches of all
+ * modalities, output launch storing straight into xhat_dev]; conv decoders go through avae_decode's path.  Calls on one handle
+ * must be issued on one stream at a time (the published pointers belong to the latest call). */
 int avae_generate(avae_handle* h, const float* z_dev, int32_t rows, float* const* xhat_dev, void* stream);
 /* reconstruct (vae_assoc.py:421-425): encode -> z = mu + exp(lv/2)*eps -> decode for modality m.
  * eps_dev [rows, n_z] or NULL (internal generator, a fresh draw per call as in the reference). */
