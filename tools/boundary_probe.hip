@@ -34,6 +34,18 @@ __global__ void touch_scalar(const int* buf, int shift, int* sink) {
     if (v == 0x7fffffff && threadIdx.x == 0) sink[0] = v;
 }
 
+// the producer side of an activation hand-over: the previous kernel WRITES the line (32 lanes x 4 bytes), plain or written through
+__global__ void write_plain(int* buf, int shift) {
+    if (threadIdx.x < 32) buf[((blockIdx.x + shift) % kWG) * kLineInts + threadIdx.x] = (int)threadIdx.x;
+}
+__global__ void write_through(int* buf, int shift) {
+    if (threadIdx.x < 32) {
+        int* p = buf + ((blockIdx.x + shift) % kWG) * kLineInts + threadIdx.x;
+        const int v = (int)threadIdx.x;
+        asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+    }
+}
+
 __global__ void read_scalar(const int* buf, long long* out, int* sink) {
     const int* p = buf + blockIdx.x * kLineInts;
     long long t0, t1;
@@ -135,6 +147,21 @@ int main() {
             b = lines();
             reader(b); reader(b); std::snprintf(name, sizeof name, "%s, the same reader twice (second run)", path); report(name);
         }
+    }
+    std::printf("---- a line WRITTEN by the previous kernel, read by the vector path\n");
+    for (int rep = 0; rep < 2; ++rep) {
+        int* b = const_cast<int*>(lines());
+        hipLaunchKernelGGL(write_plain, dim3(kWG), dim3(64), 0, s, b, 0);
+        hipLaunchKernelGGL(read_vec, dim3(kWG), dim3(64), 0, s, b, out, sink); report("plain stores, same XCD");
+        b = const_cast<int*>(lines());
+        hipLaunchKernelGGL(write_through, dim3(kWG), dim3(64), 0, s, b, 0);
+        hipLaunchKernelGGL(read_vec, dim3(kWG), dim3(64), 0, s, b, out, sink); report("write-through (sc0 sc1) stores, same XCD");
+        b = const_cast<int*>(lines());
+        hipLaunchKernelGGL(write_plain, dim3(kWG), dim3(64), 0, s, b, 1);
+        hipLaunchKernelGGL(read_vec, dim3(kWG), dim3(64), 0, s, b, out, sink); report("plain stores, OTHER XCD");
+        b = const_cast<int*>(lines());
+        hipLaunchKernelGGL(write_through, dim3(kWG), dim3(64), 0, s, b, 1);
+        hipLaunchKernelGGL(read_vec, dim3(kWG), dim3(64), 0, s, b, out, sink); report("write-through (sc0 sc1) stores, OTHER XCD");
     }
     std::printf("---- bursts of s_load_dwordx16 (what a 256-byte work item costs)\n");
     int* buf2; OK(hipMalloc(&buf2, kWG * 512 * 8)); OK(hipMemset(buf2, 0, kWG * 512 * 8));
