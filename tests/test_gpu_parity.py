@@ -641,6 +641,25 @@ def test_generate_serving_buckets(V, monkeypatch, env):
             assert torch.equal(gen[m], o), (rows, m)
 
 
+@pytest.mark.parametrize("B", [100, 33, 7])
+def test_generate_serving_odd_batch_sizes(V, B):
+    """The serving path (staging launch with the decoder's first layer as its tail product, 32-row tiles) with batch sizes that are
+    not multiples of 32 and smaller than the 64-row bucket: bitwise the per-modality avae_decode path, both dtypes."""
+    archs = [make_arch("image", 784, 96, 80, 12), make_arch("joint", 147, 40, 24, 12)]
+    rng = np.random.default_rng(41)
+    for dtype in ("fp32", "bf16"):
+        mb = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="softplus", batch_size=B, compute_dtype=dtype, seed=4)
+        for rows in (1, B - 1, B, B + 1, 3 * B + 2):
+            if rows < 1:
+                continue
+            z = torch.as_tensor(rng.standard_normal((rows, 12)).astype(np.float32)).cuda()
+            gen = mb.generate(z)
+            for m in range(2):
+                o = torch.empty((rows, archs[m]["n_input"]), dtype=torch.float32, device="cuda")
+                assert mb._L.avae_decode(mb._h, m, z.data_ptr(), rows, o.data_ptr(), mb._stream()) == 0
+                assert torch.equal(gen[m], o), (dtype, B, rows, m)
+
+
 def test_strided_modalities_from_one_matrix(V):
     """train() hands column slices of one [B, 931] matrix (vae_assoc.py:510,543): no copies."""
     archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
