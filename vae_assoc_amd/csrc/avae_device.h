@@ -199,7 +199,11 @@ struct PrepArgs {
 
 // Fixed-order sum of the split-K slices of a weight gradient: dst[i] = sum_s src[s*stride + i]  (no atomics: reproducible).
 struct ReduceSeg { float* dst; const float* src; int n, parts; long long stride; int block_base;
-                   int dst_ld; };   // dst_ld > 0: element i goes to dst[i * dst_ld] (a one-column gradient in a padded matrix)
+                   int dst_ld;      // dst_ld > 0: element i goes to dst[i * dst_ld] (a one-column gradient in a padded matrix)
+                   int colsum;      // 1: k_colsum's tree (many short partial vectors), 0: k_reduce's slice sum -- one launch may carry both (k_sums)
+                   // slice sums of an adjoint-frame filter gradient [Cin][(kh', kw', co)] (leading dim perm_ldga) go straight to the
+                   // gradient buffer's layout [(kh, kw, ci)][co] (leading dim perm_ld, kh = k-1-kh'): perm_k > 0, dst = that matrix
+                   int perm_k, perm_cin, perm_cout, perm_ldga, perm_ld; };
 constexpr int kMaxReduceSegs = 40;          // up to 9 split conv stages per modality x 4 modalities (+ bias sums)
 struct ReduceArgs { ReduceSeg seg[kMaxReduceSegs]; int n_seg; };
 
@@ -319,6 +323,7 @@ void launch_adam(int compute_dtype, const AdamArgs& a, int n_blocks, hipStream_t
 void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s);
 const void* prep_kernel(int compute_dtype);          // for hipGraphExecKernelNodeSetParams on the captured staging node
 void launch_fill(void* base, int elem_bytes, unsigned bits, long long start, long long stride, int count, hipStream_t s);
+void launch_sums(const ReduceArgs& a, int n_blocks, hipStream_t s);
 void launch_reduce(const ReduceArgs& a, int n_blocks, hipStream_t s);
 
 }  // namespace avae

@@ -1388,27 +1388,40 @@ void build_training_plan(avae_handle* h) {
                 g.block_base = base; base += (g.n + 3) / 4;
             }
             R.blocks = base;
+            for (int i = 0; i < R.ra.n_seg; ++i) { R.ra.seg[i].colsum = 1; R.ra.seg[i].perm_k = 0; }
             if (base > 0) h->wgrad.push_back(R);
         }
         {   // the split-K slices of the conv stages' weight gradients -> the gradient buffer, in fixed order
             Launch R;
             R.name = "wgrad_reduce"; R.type = 3;
             int base = 0;
+            // (the column sums above write other destinations: when both exist they share one launch, k_sums)
+            Launch* prev = (!h->wgrad.empty() && h->wgrad.back().type == 5 && !std::getenv("AVAE_NO_SUMS_MERGE")) ? &h->wgrad.back() : nullptr;
+            if (prev) { R = *prev; R.name = prev->name + "+wgrad_reduce"; R.type = 9; base = prev->blocks; }
             for (const WorkItem& w : wg) if (w.ksplit > 1) {
                 if (R.ra.n_seg >= kMaxReduceSegs) throw Err("internal error: too many split weight gradients");
                 ReduceSeg& g = R.ra.seg[R.ra.n_seg++];
                 g.dst = reinterpret_cast<float*>(w.out0); g.src = reinterpret_cast<const float*>(w.out1);
                 g.n = w.M * w.ld0; g.parts = w.ksplit; g.stride = (long long)w.M * w.ld0;
+                g.colsum = 0; g.perm_k = 0;
+                // an adjoint-frame filter gradient: its slice sums go straight into the gradient buffer's layout (no k_gperm pass)
+                if (!std::getenv("AVAE_NO_SUMS_MERGE"))
+                    for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj && st.aksplit > 1 && g.dst == h->at<float>(st.Gadj)) {
+                        g.dst = h->grad() + st.d.master;
+                        g.perm_k = st.g.k; g.perm_cin = st.g.Cin; g.perm_cout = st.d.out; g.perm_ldga = st.ldga; g.perm_ld = st.d.ld;
+                    }
                 g.block_base = base; base += (g.n / 4 + kThreads - 1) / kThreads;
             }
             R.blocks = base;
-            if (base > 0) h->wgrad.push_back(R);
+            if (prev && base > prev->blocks) *prev = R;              // merged: replaces the column-sum launch
+            else if (!prev && base > 0) h->wgrad.push_back(R);
         }
         {   // adjoint-frame filter gradients -> the gradient buffer's layout
             Launch L;
             L.name = "conv_wgrad_perm"; L.type = 7;
             int base = 0;
             for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {
+                if (st.aksplit > 1 && !std::getenv("AVAE_NO_SUMS_MERGE")) continue;      // permuted by its slice sum (ReduceSeg::perm_*)
                 GpermSeg& g = L.gp.seg[L.gp.n_seg++];
                 g.Gadj = h->at<float>(st.Gadj); g.G = h->grad() + st.d.master; g.ldga = st.ldga; g.ld = st.d.ld;
                 g.k = st.g.k; g.Cin = st.g.Cin; g.Cout = st.d.out;
@@ -1590,6 +1603,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         else if (L.type == 6) launch_wadj(h->cfg.compute_dtype, L.wa, L.blocks, s);
         else if (L.type == 7) launch_gperm(L.gp, L.blocks, s);
         else if (L.type == 8) launch_rowsum(h->cfg.compute_dtype, L.rs, L.blocks, s);
+        else if (L.type == 9) launch_sums(L.ra, L.blocks, s);
         else if (L.tn) launch_grouped_tn(h->cfg.compute_dtype, L.cfg, L.targs, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         LAUNCH_OK(L.name);

@@ -1953,12 +1953,8 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
 // Column sums of per-workgroup partial sums (the direct stage's filter gradient, the bias row sums):
 // dst[i*dst_ld] = sum_s src[s*stride + i].  A workgroup takes 4 elements; lane group q of 64 adds slices q, q+64, ... in order,
 // then the 64 group sums are added in order: a fixed tree, reproducible.
-__global__ void __launch_bounds__(kThreads) k_colsum(ReduceArgs a) {
-    __shared__ float red[64][5];
-    const int bid = blockIdx.x, tid = threadIdx.x;
-    int it = 0;
-    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
-    const ReduceSeg& g = a.seg[it];
+__device__ __forceinline__ void colsum_body(const ReduceSeg& g, int bid, float (*red)[5]) {
+    const int tid = threadIdx.x;
     const int e = tid & 3, q = tid >> 2;
     const int i = (bid - g.block_base) * 4 + e;
     float acc = 0.0f;
@@ -1978,6 +1974,13 @@ __global__ void __launch_bounds__(kThreads) k_colsum(ReduceArgs a) {
         for (int k = 1; k < 64; ++k) t += red[k][e];
         g.dst[(size_t)i * (g.dst_ld > 0 ? g.dst_ld : 1)] = t;
     }
+}
+__global__ void __launch_bounds__(kThreads) k_colsum(ReduceArgs a) {
+    __shared__ float red[64][5];
+    const int bid = blockIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
+    colsum_body(a.seg[it], bid, red);
 }
 
 void launch_colsum(const ReduceArgs& a, int n_blocks, hipStream_t s) {
@@ -2014,11 +2017,7 @@ void launch_serve(int compute_dtype, const ServeArgs& a, const ServeSlot& call, 
 }
 
 // ------------------------------------------------------------------ split-K reduction
-__global__ void __launch_bounds__(kThreads) k_reduce(ReduceArgs a) {
-    const int bid = blockIdx.x;
-    int it = 0;
-    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
-    const ReduceSeg& g = a.seg[it];
+__device__ __forceinline__ void reduce_body(const ReduceSeg& g, int bid) {
     const int i = ((bid - g.block_base) * kThreads + (int)threadIdx.x) * 4;       // n and stride are multiples of 4
     if (i >= g.n) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -2038,7 +2037,38 @@ __global__ void __launch_bounds__(kThreads) k_reduce(ReduceArgs a) {
                 for (int e = 0; e < 4; ++e) acc[e] += v[u][e];
             }
     }
+    if (g.perm_k > 0) {          // (k_gperm's index map, applied as the sums are stored)
+        const int KA = g.perm_k * g.perm_k * g.perm_cout;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = i + e, ci = idx / g.perm_ldga, r = idx - ci * g.perm_ldga;
+            if (r < KA) {
+                const int kp = r / g.perm_cout, co = r - kp * g.perm_cout, kh = kp / g.perm_k, kw = kp - kh * g.perm_k;
+                g.dst[(size_t)(((g.perm_k - 1 - kh) * g.perm_k + (g.perm_k - 1 - kw)) * g.perm_cin + ci) * g.perm_ld + co] = acc[e];
+            }
+        }
+        return;
+    }
     store4<float>(g.dst + i, acc);
+}
+__global__ void __launch_bounds__(kThreads) k_reduce(ReduceArgs a) {
+    const int bid = blockIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
+    reduce_body(a.seg[it], bid);
+}
+// both kinds of sums behind the weight-gradient launches in ONE launch (they are independent: different destinations)
+__global__ void __launch_bounds__(kThreads) k_sums(ReduceArgs a) {
+    __shared__ float red[64][5];
+    const int bid = blockIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
+    if (a.seg[it].colsum) colsum_body(a.seg[it], bid, red);         // (block-uniform branch: the barrier inside is safe)
+    else reduce_body(a.seg[it], bid);
+}
+void launch_sums(const ReduceArgs& a, int n_blocks, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    AVAE_LAUNCH(k_sums, dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
 void launch_reduce(const ReduceArgs& a, int n_blocks, hipStream_t s) {
