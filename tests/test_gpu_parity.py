@@ -320,6 +320,9 @@ def test_config_c5_three_modalities_lambda_sweep(V, lam):
          binary=[True, False, True, False], w=[1.0, 2.0, 3.0, 4.0], lam=0.3, act="identity", B=33),
     dict(archs=[make_arch("a", 128, 0, 0, 16, n_hidden=[64, 128]), make_arch("b", 64, 0, 0, 16, n_hidden=[192])],
          binary=[True, False], w=[1.0, 1.0], lam=0.2, act="softplus", B=96),        # fan-ins of k*64: bias gradient from the ones MFMA
+    dict(archs=[make_arch("a", 50, 0, 0, 7, n_hidden=[40, 36, 32, 28, 24, 20, 16, 12]), make_arch("b", 33, 0, 0, 7, n_hidden=[30, 28, 26, 24, 22, 20, 18, 16]),
+                make_arch("c", 21, 0, 0, 7, n_hidden=[20, 19, 18, 17, 16, 15, 14, 13]), make_arch("d", 9, 0, 0, 7, n_hidden=[12, 12, 12, 12, 12, 12, 12, 12])],
+         binary=[True, False, True, False], w=[1.0, 0.5, 2.0, 1.5], lam=0.4, act="softplus", B=20),   # the ABI's maxima: 4 modalities x 8 hidden layers
 ])
 def test_shapes_and_options(V, case, dtype):
     check_step_parity(V, case["archs"], case["binary"], case["w"], case["lam"], case["act"], case["B"], dtype)
