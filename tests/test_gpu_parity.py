@@ -486,11 +486,12 @@ def test_tail_product_route(V, monkeypatch, dtype, B):
     assert "bwd_dec1_latent+bwd_head" in names, names      # ([dmu | dlv] = 40 columns: one 128-byte K tile of bf16, two of fp32)
 
 
-@pytest.mark.parametrize("env", [{"AVAE_NO_THIN": "1"}, {"AVAE_NO_ADJ": "1"}, {"AVAE_NO_THIN": "1", "AVAE_NO_ADJ": "1"}, {"AVAE_NO_SINK": "1"}, {"AVAE_NO_SUMS_MERGE": "1"}])
+@pytest.mark.parametrize("env", [{"AVAE_NO_THIN": "1"}, {"AVAE_NO_ADJ": "1"}, {"AVAE_NO_THIN": "1", "AVAE_NO_ADJ": "1"}, {"AVAE_NO_SINK": "1"}, {"AVAE_NO_SUMS_MERGE": "1"}, {"AVAE_NO_WADJ_FOLD": "1"}])
 def test_planner_switches_conv_routes(V, monkeypatch, env):
     """Conv stages through the patch-matrix route instead of the direct / adjoint-frame ones; the MLP modality's hidden layers as
     launches of their own instead of riding in the conv modality's GEMM launches (AVAE_NO_SINK); the sums behind the weight
-    gradients as k_colsum + k_reduce + k_gperm launches instead of one k_sums launch (AVAE_NO_SUMS_MERGE): same parity."""
+    gradients as k_colsum + k_reduce + k_gperm launches instead of one k_sums launch (AVAE_NO_SUMS_MERGE); the adjoint filter
+    shadows by a k_wadj launch instead of by k_adam's pass (AVAE_NO_WADJ_FOLD): same parity."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     img = dict(make_arch("image", 784, 8, 24, 6), hidden_conv=True, n_hidden_gener_1=24, n_hidden_gener_2=8)

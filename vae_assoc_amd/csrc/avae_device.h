@@ -155,6 +155,11 @@ struct AdamItem {
     int ld, ldt;
     int tiles_r, tiles_c, tile_base;
     int ldw;                 // leading dim of the W shadow (>= ld: see spread_ld in avae_host.hip)
+    // transposed-conv stages on the adjoint-frame route (adj_k > 0): the same pass also writes the adjoint filter shadows k_wadj
+    // used to build in a launch of its own -- element (row (kh_m, kw_m, ci), col co) of the matrix goes, with kh = k-1-kh_m,
+    // kw = k-1-kw_m and r = (kh*k + kw)*cols + co, to Wadj[ci][r] and Wf[r][ci]
+    void* Wadj; void* Wf;
+    int ldadj, ldf, adj_k, adj_cin;
 };
 
 constexpr int kMaxAdamItems = 80;      // kMaxMod * (2*AVAE_MAX_HIDDEN + 2)

@@ -1075,7 +1075,7 @@ void build_training_plan(avae_handle* h) {
             g.block_base = base; base += (st.g.Cin * st.g.k * st.g.k * st.d.out + kThreads - 1) / kThreads;
         }
         L.blocks = base;
-        if (base > 0) h->fwd.push_back(L);
+        if (base > 0 && std::getenv("AVAE_NO_WADJ_FOLD")) h->fwd.push_back(L);       // default: k_adam writes these shadows (AdamItem::Wadj)
     }
     if (any_conv) {   // deconv decoder: (im2col of the dilated input, GEMM + bias + sigmoid) x 4, then flatten for the dense output
         for (int i = 0; i < 4; ++i) {
@@ -1481,7 +1481,13 @@ void build_training_plan(avae_handle* h) {
     for (const Mod& md : h->mods) {
         if (md.conv) {
             for (const ConvStage& st : md.cenc) add(st.d);
-            for (const ConvStage& st : md.cdec) add(st.d);
+            for (const ConvStage& st : md.cdec) {
+                add(st.d);
+                if (st.adj && !std::getenv("AVAE_NO_WADJ_FOLD")) {       // adjoint filter shadows by the same pass (no k_wadj launch)
+                    AdamItem& a = h->adam_items.back();
+                    a.Wadj = h->at<void>(st.Wadj); a.Wf = h->at<void>(st.Wf); a.ldadj = st.ldadj; a.ldf = st.ldf; a.adj_k = st.g.k; a.adj_cin = st.g.Cin;
+                }
+            }
             continue;
         }
         for (const Dense& d : md.enc) add(d);

@@ -1410,6 +1410,17 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
                 store_row<float>(w.v + off, v, nv);
             }
             store_row<CT>(reinterpret_cast<CT*>(w.W) + (size_t)grow * w.ldw + gcol, th, w.cols - gcol);
+            if (w.adj_k > 0 && grow < w.adj_k * w.adj_k * w.adj_cin) {       // (not the bias row)
+                const int kp = grow / w.adj_cin, ci = grow - kp * w.adj_cin, kh = w.adj_k - 1 - kp / w.adj_k, kw = w.adj_k - 1 - kp % w.adj_k;
+                const int r = (kh * w.adj_k + kw) * w.cols + gcol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gcol + e < w.cols) {
+                        const CT v = to_ct<CT>(th[e]);
+                        reinterpret_cast<CT*>(w.Wadj)[(size_t)ci * w.ldadj + r + e] = v;
+                        reinterpret_cast<CT*>(w.Wf)[(size_t)(r + e) * w.ldf + ci] = v;
+                    }
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) T[r][c4 + e] = th[e];
