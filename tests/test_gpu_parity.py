@@ -462,6 +462,20 @@ def test_planner_switches_big_launches(V, monkeypatch, env):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_lean_small_tile_kernel(V, monkeypatch, dtype):
+    """The chain's hidden-layer launches of small nets run on k_small (32x32 tiles, kind and transfer function at compile time,
+    register epilogue); AVAE_NO_LEAN=1 keeps them on k_grouped's 32x32 instance.  Both pass the oracle parity and agree bitwise
+    (same tiles, same K order, same rounding points); relu and softplus, a partial last row tile."""
+    archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
+    for act in ("relu", "softplus"):
+        monkeypatch.delenv("AVAE_NO_LEAN", raising=False)
+        on, _e, X, eps = check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, act, 100, dtype, steps=1)
+        monkeypatch.setenv("AVAE_NO_LEAN", "1")
+        off, _e, X, eps = check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, act, 100, dtype, steps=1)
+        assert np.array_equal(on.get_grads(), off.get_grads()) and np.array_equal(on.get_params(), off.get_params()), act
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B", [256, 100])
 def test_tail_product_route(V, monkeypatch, dtype, B):
     """Small nets: the decoder's first layer rides in the heads' launch and the heads' input gradient in bwd_dec1_latent's (the

@@ -1276,6 +1276,91 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
     }
 }
 
+// ------------------------------------------------------------------ the lean 32x32 kernel (small nets' hidden layers)
+// C1 / C2 / C5 run chains of launches whose K loops are a third of their time; the rest is once-through code, and on a lone wave per
+// SIMD every instruction of it is ~5 cycles and every cold 64-byte line of code a miss (a handful of never-taken
+// branches cost 0.7 us per launch).  k_grouped's 32x32 instance carries every kind's epilogue behind a switch and stages its
+// result through LDS; this kernel is the same product for the two kinds that make up the chain -- K_FWD_HIDDEN, K_DGRAD_HIDDEN --
+// and nothing else: kind and transfer function are template parameters, the MFMA operands are swapped (row on the lane, four
+// consecutive columns in the registers) and the 16x16 block of a wave goes from the accumulator straight to memory.  Same tiles,
+// same K order, same rounding points as k_grouped<CT, 32, 32, 4>: bitwise the same results (AVAE_NO_LEAN=1 for A/B).
+template <typename CT, int KIND, int ACT>
+__global__ void __launch_bounds__(kThreads) k_small(const LaunchArgs args, unsigned long long* stamps, int launch_id) {
+    constexpr int BM = 32, RING = 4, ES = (int)sizeof(CT), NCH = 2;
+    constexpr int kStage = 64 * kTileBytesK;                   // A rows 0..31, B rows 32..63 of one K tile
+    unsigned char* smem = avae_dyn_smem;
+#ifdef AVAE_STAMPS
+    unsigned long long sv[kStampWords] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    AVAE_STAMP(0)
+    const int part = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const WorkItem w = args.items[blockIdx.y];
+    asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.aux0), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.ldx));
+    int t;
+    {
+        const int nt = w.tiles_m * w.tiles_n;
+        const int q = nt >> 3, r = nt & 7;
+        if (idx >= q + (part < r ? 1 : 0)) return;
+        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tm = t / w.tiles_n, tn = t - tm * w.tiles_n;
+    const int m0 = tm * BM, n0 = tn * 32;
+    const int nk = (w.K * ES) / kTileBytesK;
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    // this wave's two 1-KiB pieces of a stage: rows 8 wave .. of the A part and of the B part (chunk c of row r at c ^ ((r >> 1) & 7))
+    const int prow = wave * 8 + (lane >> 3), lc = ((lane & 7) ^ ((prow >> 1) & 7)) * 16;
+    const unsigned char* srcA = reinterpret_cast<const unsigned char*>(w.A) + (size_t)(m0 + prow) * w.lda * ES + lc;
+    const unsigned char* srcB = reinterpret_cast<const unsigned char*>(w.B) + (size_t)(n0 + prow) * w.ldb * ES + lc;
+    // dgrad: act'(stored output of the layer below), 4 consecutive columns of this lane's row -- older than every tile, so the counted
+    // waits below stay exact and its round trip hides behind the first tile's
+    const int orow = m0 + wr * 16 + fr, ocol = n0 + wc * 16 + 4 * fq;
+    typename Quad<CT>::raw yq;
+    if constexpr (KIND == 1)
+        yq = *reinterpret_cast<const typename Quad<CT>::raw*>(reinterpret_cast<const CT*>(w.aux0) + (size_t)min(orow, w.M - 1) * w.ldx + min(ocol, w.ldx - 4));
+#define AVAE_S_DMA(kt, buf)                                                                                             \
+    { __builtin_amdgcn_global_load_lds((gp_t)(srcA + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kStage + wave * 1024), 16, 0, 0);          \
+      __builtin_amdgcn_global_load_lds((gp_t)(srcB + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kStage + (4 + wave) * 1024), 16, 0, 0); }
+    AVAE_STAMP(1)
+    const int npro = nk < RING - 1 ? nk : RING - 1;
+    for (int p = 0; p < npro; ++p) AVAE_S_DMA(p, p)
+    const int sw0 = (fq ^ (fr >> 1)) * 16;
+    const int aoff = (wr * 16 + fr) * kTileBytesK, boff = (32 + wc * 16 + fr) * kTileBytesK;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // two younger tiles (2 pieces each) may be on their way
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (kt == 0) { AVAE_STAMP(2) }
+        const unsigned char* Sb = smem + buf * kStage;
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(Sb + aoff + sw0), b0 = *reinterpret_cast<const u32x4*>(Sb + boff + sw0);
+        const int fill = buf == 0 ? RING - 1 : buf - 1;
+        if (kt + RING - 1 < nk) AVAE_S_DMA(kt + RING - 1, fill)
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(Sb + aoff + (sw0 ^ 64)), b1 = *reinterpret_cast<const u32x4*>(Sb + boff + (sw0 ^ 64));
+        mma<CT>(b0, a0, acc);                                  // swapped: acc[e] = C[row fr][col 4 fq + e]
+        mma<CT>(b1, a1, acc);
+        buf = buf + 1 == RING ? 0 : buf + 1;
+    }
+#undef AVAE_S_DMA
+    AVAE_STAMP(3)
+    if (orow < w.M && ocol < w.N) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (KIND == 0) v[e] = act_fwd_t<ACT>(acc[e]);
+            else v[e] = acc[e] * act_bwd_t<ACT>(quad_elem<CT>(yq, e));
+        }
+        store_row<CT>(reinterpret_cast<CT*>(w.out0) + (size_t)orow * w.ld0 + ocol, v, w.N - ocol);
+    }
+    AVAE_STAMP(4)
+    AVAE_STAMP_FLUSH()
+}
+
 // Timing mode (avae_timing_enable): the host arms one (start, stop) event pair per launch; the launch then
 // goes through hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin/end timestamps --
 // the same signal times rocprofv3 --kernel-trace reports -- instead of bracketing it with marker packets.
@@ -1294,6 +1379,20 @@ thread_local LaunchEvents t_launch_events = {nullptr, nullptr};
 template <typename K> static void set_max_lds(K kernel) {
     // > 64 KiB of dynamic LDS has to be opted into once per kernel
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+template <typename CT, int KIND>
+static void launch_small_act(int act, const LaunchArgs& args, dim3 grid, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id) {
+    const dim3 block(kThreads);
+    if (act == AVAE_ACT_RELU) AVAE_LAUNCH((k_small<CT, KIND, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, stamps, launch_id);
+    else AVAE_LAUNCH((k_small<CT, KIND, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, stamps, launch_id);
+}
+// tile_cfg 7 (host: finish_launch): every item of the launch is of ONE of the two kinds, with relu or softplus
+void launch_small(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id) {
+    const dim3 grid(grid_x, grid_y);
+    const int kind = args.items[0].kind == K_DGRAD_HIDDEN ? 1 : 0, act = args.items[0].act;
+    if (compute_dtype == AVAE_BF16) { if (kind) launch_small_act<__bf16, 1>(act, args, grid, lds_bytes, s, stamps, launch_id); else launch_small_act<__bf16, 0>(act, args, grid, lds_bytes, s, stamps, launch_id); }
+    else { if (kind) launch_small_act<float, 1>(act, args, grid, lds_bytes, s, stamps, launch_id); else launch_small_act<float, 0>(act, args, grid, lds_bytes, s, stamps, launch_id); }
 }
 
 // Refill-issuing waves of the 8-wave K-major (weight-gradient) tiles (see k_grouped).  Measured on C4: wgrad 143 -> 135 us with 4
