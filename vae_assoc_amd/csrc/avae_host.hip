@@ -788,6 +788,12 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
             for (int i = first; i < first + count; ++i)
                 lean = lean && items[i].kind == k0 && items[i].act == a0 && !items[i].bias_ep && items[i].K > 0;
             if (lean && (k0 == K_FWD_HIDDEN || k0 == K_DGRAD_HIDDEN) && (a0 == AVAE_ACT_RELU || a0 == AVAE_ACT_SOFTPLUS)) L.cfg = 7;
+            bool loss = false, only_loss = true;                  // the output + loss launch (with the latent item riding in it): k_small_loss
+            for (int i = first; i < first + count; ++i) {
+                loss = loss || items[i].kind == K_FWD_OUT_LOSS;
+                only_loss = only_loss && ((items[i].kind == K_FWD_OUT_LOSS && !items[i].bias_ep && items[i].K > 0) || items[i].kind == K_LATENT);
+            }
+            if (L.cfg == 5 && loss && only_loss && !std::getenv("AVAE_NO_LEAN_LOSS")) L.cfg = 9;
         }
     }
     if (L.cfg == 1 && need128 && !std::getenv("AVAE_NO_64x128")) {      // wide-latent head launches: few tiles, K loop = load latency
@@ -809,8 +815,8 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         }
         if (loss_only && t >= 192) L.cfg = 6;
     }
-    const int T = (L.cfg == 1 || L.cfg == 2 || L.cfg == 4) ? 128 : (L.cfg == 5 || L.cfg == 7) ? 32 : 64;
-    const int TM = (L.cfg == 2 || L.cfg == 6) ? 256 : (L.cfg == 3 || L.cfg == 5 || L.cfg == 7) ? 32 : L.cfg == 4 ? 64 : T;
+    const int T = (L.cfg == 1 || L.cfg == 2 || L.cfg == 4) ? 128 : (L.cfg == 5 || L.cfg == 7 || L.cfg == 9) ? 32 : 64;
+    const int TM = (L.cfg == 2 || L.cfg == 6) ? 256 : (L.cfg == 3 || L.cfg == 5 || L.cfg == 7 || L.cfg == 9) ? 32 : L.cfg == 4 ? 64 : T;
     if ((L.cfg == 2 || L.cfg == 6) && !std::getenv("AVAE_NO_BIAS_EP"))      // 8-wave NT tiles: bias in the epilogue where that saves a K tile
         for (int i = first; i < first + count; ++i) {
             WorkItem& w = items[i];
@@ -843,7 +849,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
     {
         bool two = false;
         for (int i = first; i < first + count; ++i) two = two || items[i].kind == K_FWD_HEAD || items[i].kind == K_DGRAD_LATENT || items[i].kind == K_SERVE_Z;
-        L.lds = L.cfg == 7 ? 4 * 64 * kTileBytesK : tile_lds_bytes(L.cfg, two);
+        L.lds = L.cfg == 7 ? 4 * 64 * kTileBytesK : L.cfg == 9 ? 4 * 64 * kTileBytesK + 64 : tile_lds_bytes(L.cfg, two);
     }
     L.tn = true;
     for (int i = first; i < first + count; ++i) L.tn = L.tn && items[i].kind == K_WGRAD;
@@ -1617,6 +1623,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         else if (L.type == 7) launch_gperm(L.gp, L.blocks, s);
         else if (L.type == 8) launch_rowsum(h->cfg.compute_dtype, L.rs, L.blocks, s);
         else if (L.type == 9) launch_sums(L.ra, L.blocks, s);
+        else if (L.cfg == 9) launch_small_loss(h->cfg.compute_dtype, L.args, L.grid_x, L.grid_y, L.lds, s, stamps, stamp_base + k);
         else if (L.cfg == 7) launch_small(h->cfg.compute_dtype, L.args, L.grid_x, L.grid_y, L.lds, s, stamps, stamp_base + k);
         else if (L.tn) launch_grouped_tn(h->cfg.compute_dtype, L.cfg, L.targs, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);

@@ -237,6 +237,25 @@ template <int NW = 4> __device__ __forceinline__ float block_sum(float v, float*
     return t;
 }
 
+// Reconstruction loss of one element and its gradient w.r.t. the logit -- ONE definition for the three kernels that carry the loss
+// epilogue, with floating-point contraction off inside it, so that every route rounds alike (the routes are checked against each other
+// bitwise).  sl = scale * loss, da = scale * dloss/da.
+// Bernoulli: -(x log(1e-3+p) + (1-x) log(1e-3+1-p)), p = sigmoid(a)  (vae_assoc.py:321-324);  Gaussian: (x-a)^2 / 2  (:327-328)
+__device__ __forceinline__ void loss_bernoulli(float a, float x, float sc, float& sl, float& da) {
+#pragma clang fp contract(off)
+    const float en = fexp(-a), p = frcp(1.0f + en);
+    const float lp = 1e-3f + p, lq = 1e-3f + 1.0f - p;
+    const float loss = -(x * flog(lp) + (1.0f - x) * flog(lq));
+    sl = sc * loss;
+    da = sc * p * (1.0f - p) * ((1.0f - x) * lp - x * lq) * frcp(lp * lq);
+}
+__device__ __forceinline__ void loss_gauss(float a, float x, float sc, float& sl, float& da) {
+#pragma clang fp contract(off)
+    const float df = a - x;
+    sl = sc * 0.5f * df * df;
+    da = sc * df;
+}
+
 // Index of element (r, c) of an fp32 accumulator tile in LDS (row stride LDC = BN + 4).  Columns are
 // XOR-swizzled by the row's 8-row group in units of 4 floats: a row access (16-B groups) stays
 // aligned and contiguous per group, while the column walk of the transposed store -- lanes 8 rows
@@ -1018,20 +1037,18 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
                 if (w.binary) {
                     regep_store<CT, MI, NI>(acc, dA, w.ld0, M, N, ep_row, cwave, lane, [&](int i, int j, int r, float a0) {
                         const bool ok = ep_row + 16 * i < M && ep_col + 16 * j + r < N;
-                        const float a = a0 + bias[j][r], x = xv[i][j][r];
-                        const float en = fexp(-a), p = frcp(1.0f + en);
-                        const float lp = 1e-3f + p, lq = 1e-3f + 1.0f - p;
-                        const float loss = -(x * flog(lp) + (1.0f - x) * flog(lq));
-                        const float da = sc * p * (1.0f - p) * ((1.0f - x) * lp - x * lq) * frcp(lp * lq);
-                        csum += ok ? sc * loss : 0.0f;
+                        float sl, da;
+                        loss_bernoulli(a0 + bias[j][r], xv[i][j][r], sc, sl, da);
+                        csum += ok ? sl : 0.0f;
                         return ok ? da : 0.0f;
                     });
                 } else {
                     regep_store<CT, MI, NI>(acc, dA, w.ld0, M, N, ep_row, cwave, lane, [&](int i, int j, int r, float a0) {
                         const bool ok = ep_row + 16 * i < M && ep_col + 16 * j + r < N;
-                        const float df = a0 + bias[j][r] - xv[i][j][r];
-                        csum += ok ? sc * 0.5f * df * df : 0.0f;
-                        return ok ? sc * df : 0.0f;
+                        float sl, da;
+                        loss_gauss(a0 + bias[j][r], xv[i][j][r], sc, sl, da);
+                        csum += ok ? sl : 0.0f;
+                        return ok ? da : 0.0f;
                     });
                 }
                 const float total = block_sum<NW>(csum, red);
@@ -1136,19 +1153,18 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
         if (w.binary) {
             tile_pass<CT, float, true, false, BM, BN>(Cs, dA, w.ld0, X, w.ldx, M, N, m0, n0,
                 [&csum, sc](float a, float x, bool ok) {
-                    const float en = fexp(-a), p = frcp(1.0f + en);
-                    const float lp = 1e-3f + p, lq = 1e-3f + 1.0f - p;
-                    const float loss = -(x * flog(lp) + (1.0f - x) * flog(lq));
-                    const float da = sc * p * (1.0f - p) * ((1.0f - x) * lp - x * lq) * frcp(lp * lq);
-                    csum += ok ? sc * loss : 0.0f;
+                    float sl, da;
+                    loss_bernoulli(a, x, sc, sl, da);
+                    csum += ok ? sl : 0.0f;
                     return ok ? da : 0.0f;
                 });
         } else {
             tile_pass<CT, float, true, false, BM, BN>(Cs, dA, w.ld0, X, w.ldx, M, N, m0, n0,
                 [&csum, sc](float a, float x, bool ok) {
-                    const float df = a - x;
-                    csum += ok ? sc * 0.5f * df * df : 0.0f;
-                    return ok ? sc * df : 0.0f;
+                    float sl, da;
+                    loss_gauss(a, x, sc, sl, da);
+                    csum += ok ? sl : 0.0f;
+                    return ok ? da : 0.0f;
                 });
         }
         const float total = block_sum(csum, red);
@@ -1379,6 +1395,99 @@ thread_local LaunchEvents t_launch_events = {nullptr, nullptr};
 template <typename K> static void set_max_lds(K kernel) {
     // > 64 KiB of dynamic LDS has to be opted into once per kernel
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// The small nets' output + loss launch on the same lean frame (tile configuration 9): K_FWD_OUT_LOSS items (Bernoulli or Gaussian per
+// item) and the K_LATENT item that rides with them.  The exact fp32 inputs the loss compares with are fetched ahead of the first tile;
+// loss, gradient and the tile's cost partial come from the accumulators (one LDS round for the fixed-order block sum).
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_small_loss(const LaunchArgs args, unsigned long long* stamps, int launch_id) {
+    constexpr int BM = 32, RING = 4, ES = (int)sizeof(CT);
+    constexpr int kStage = 64 * kTileBytesK;
+    unsigned char* smem = avae_dyn_smem;
+    float* red = reinterpret_cast<float*>(smem + RING * kStage);
+#ifdef AVAE_STAMPS
+    unsigned long long sv[kStampWords] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    AVAE_STAMP(0)
+    const int part = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const WorkItem w = args.items[blockIdx.y];
+    asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.aux0), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.ldx));
+    int t;
+    {
+        const int nt = w.tiles_m * w.tiles_n;
+        const int q = nt >> 3, r = nt & 7;
+        if (idx >= q + (part < r ? 1 : 0)) return;
+        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx;
+    }
+    if (w.kind == K_LATENT) {
+        latent_item<4>(w, t, red);
+        AVAE_STAMP(4)
+        AVAE_STAMP_FLUSH()
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tm = t / w.tiles_n, tn = t - tm * w.tiles_n;
+    const int m0 = tm * BM, n0 = tn * 32;
+    const int nk = (w.K * ES) / kTileBytesK;
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    const int prow = wave * 8 + (lane >> 3), lc = ((lane & 7) ^ ((prow >> 1) & 7)) * 16;
+    const unsigned char* srcA = reinterpret_cast<const unsigned char*>(w.A) + (size_t)(m0 + prow) * w.lda * ES + lc;
+    const unsigned char* srcB = reinterpret_cast<const unsigned char*>(w.B) + (size_t)(n0 + prow) * w.ldb * ES + lc;
+    const int orow = m0 + wr * 16 + fr, ocol = n0 + wc * 16 + 4 * fq;
+    const f32x4 xq = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(w.aux0) + (size_t)min(orow, w.M - 1) * w.ldx + min(ocol, w.ldx - 4));
+#define AVAE_S_DMA(kt, buf)                                                                                             \
+    { __builtin_amdgcn_global_load_lds((gp_t)(srcA + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kStage + wave * 1024), 16, 0, 0);          \
+      __builtin_amdgcn_global_load_lds((gp_t)(srcB + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kStage + (4 + wave) * 1024), 16, 0, 0); }
+    AVAE_STAMP(1)
+    const int npro = nk < RING - 1 ? nk : RING - 1;
+    for (int p = 0; p < npro; ++p) AVAE_S_DMA(p, p)
+    const int sw0 = (fq ^ (fr >> 1)) * 16;
+    const int aoff = (wr * 16 + fr) * kTileBytesK, boff = (32 + wc * 16 + fr) * kTileBytesK;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (kt == 0) { AVAE_STAMP(2) }
+        const unsigned char* Sb = smem + buf * kStage;
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(Sb + aoff + sw0), b0 = *reinterpret_cast<const u32x4*>(Sb + boff + sw0);
+        const int fill = buf == 0 ? RING - 1 : buf - 1;
+        if (kt + RING - 1 < nk) AVAE_S_DMA(kt + RING - 1, fill)
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(Sb + aoff + (sw0 ^ 64)), b1 = *reinterpret_cast<const u32x4*>(Sb + boff + (sw0 ^ 64));
+        mma<CT>(b0, a0, acc);
+        mma<CT>(b1, a1, acc);
+        buf = buf + 1 == RING ? 0 : buf + 1;
+    }
+#undef AVAE_S_DMA
+    AVAE_STAMP(3)
+    // (loss_bernoulli / loss_gauss; the Bernoulli term is a mean over the batch, the Gaussian a sum over the WHOLE batch: w.scale, :340)
+    const float sc = w.scale;
+    float csum = 0.0f, v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool ok = orow < w.M && ocol + e < w.N;
+        float sl, da;
+        if (w.binary) loss_bernoulli(acc[e], xq[e], sc, sl, da);
+        else loss_gauss(acc[e], xq[e], sc, sl, da);
+        csum += ok ? sl : 0.0f;
+        v[e] = ok ? da : 0.0f;
+    }
+    if (orow < w.M && ocol < w.N) store_row<CT>(reinterpret_cast<CT*>(w.out0) + (size_t)orow * w.ld0 + ocol, v, w.N - ocol);
+    const float total = block_sum<4>(csum, red);
+    if (tid == 0) w.partial[w.slot_base + t] = total;
+    AVAE_STAMP(4)
+    AVAE_STAMP_FLUSH()
+}
+void launch_small_loss(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id) {
+    const dim3 grid(grid_x, grid_y), block(kThreads);
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_small_loss<__bf16>), grid, block, lds_bytes, s, args, stamps, launch_id);
+    else AVAE_LAUNCH((k_small_loss<float>), grid, block, lds_bytes, s, args, stamps, launch_id);
 }
 
 template <typename CT, int KIND>
