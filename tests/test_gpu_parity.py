@@ -476,6 +476,21 @@ def test_lean_small_tile_kernel(V, monkeypatch, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("nz", [32, 31, 5])
+def test_lean_head_kernels(V, monkeypatch, dtype, nz):
+    """The two fused head launches of small nets on the lean frame (k_small_head: [mu | lv] -> z -> decoder's first layer;
+    k_small_latb: dz -> [dmu | dlv] -> heads' input gradient, with the step's cost item) against k_grouped's 32x64 instance
+    (AVAE_NO_LEAN_HEAD=1): oracle parity on both routes, bitwise equal to each other.  n_z = 32 fills the 64-column tile (and makes
+    [z | 1] two K tiles of fp32), 31 is odd (unaligned dlv columns), 5 leaves most of the tile empty; a partial last row tile."""
+    archs = [make_arch("image", 300, 0, 0, nz, n_hidden=[96, 72]), make_arch("joint", 47, 0, 0, nz, n_hidden=[40])]
+    on, _e, X, eps = check_step_parity(V, archs, [True, False], [5.0, 1.0], 0.5, "softplus", 70, dtype, steps=2)
+    monkeypatch.setenv("AVAE_NO_LEAN_HEAD", "1")
+    off, _e, X, eps = check_step_parity(V, archs, [True, False], [5.0, 1.0], 0.5, "softplus", 70, dtype, steps=2)
+    assert np.array_equal(on.get_grads(), off.get_grads()) and np.array_equal(on.get_params(), off.get_params())
+    assert np.array_equal(on.cost_history(2), off.cost_history(2))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B", [256, 100])
 def test_tail_product_route(V, monkeypatch, dtype, B):
     """Small nets: the decoder's first layer rides in the heads' launch and the heads' input gradient in bwd_dec1_latent's (the

@@ -329,6 +329,11 @@ void launch_prep(int compute_dtype, const PrepArgs& a, hipStream_t s);
 const void* prep_kernel(int compute_dtype);          // for hipGraphExecKernelNodeSetParams on the captured staging node
 void launch_fill(void* base, int elem_bytes, unsigned bits, long long start, long long stride, int count, hipStream_t s);
 void launch_sums(const ReduceArgs& a, int n_blocks, hipStream_t s);
+int small_head_lds_bytes();
+void launch_small_latb(int compute_dtype, int act, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, DevState* st, hipStream_t s,
+                       unsigned long long* stamps, int launch_id);
+void launch_small_head(int compute_dtype, int act, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s,
+                       unsigned long long* stamps, int launch_id);
 void launch_small_loss(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id);
 void launch_small(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id);
 void launch_reduce(const ReduceArgs& a, int n_blocks, hipStream_t s);

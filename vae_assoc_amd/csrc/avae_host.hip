@@ -136,6 +136,7 @@ struct Launch {
     std::string name;
     int type = 0;          // 0: grouped GEMM kernel, 1: k_gather (im2col), 2: k_col2im, 3: k_reduce (split-K slices -> gradient)
     int cfg = 0, first = 0, count = 0, blocks = 0, lds = 0;
+    int lean_act = 0;      // tile configurations 10 / 11 (lean head launches): the tail's transfer function
     int grid_x = 1, grid_y = 1;   // grouped kernel: tile slot x item
     bool tn = false;              // K-major operands (the weight-gradient launches)
     LaunchArgs args{};
@@ -989,6 +990,22 @@ void build_training_plan(avae_handle* h) {
         Lp.grid_x = (max_tiles + 7) & ~7; Lp.blocks = Lp.grid_x * Lp.grid_y; Lp.args.grid_x = Lp.grid_x;
         Lp.name += "+" + Lc.name;
         ls.pop_back();
+        // the lean frame for the fused head launches (k_small_latb): every GEMM item of the kind, relu / softplus, its narrow result and
+        // the consumer's K within the 8-KiB image
+        if (!std::getenv("AVAE_NO_LEAN") && !std::getenv("AVAE_NO_LEAN_HEAD")) {
+            bool lean = true;
+            int act = -1;
+            for (int k = 0; k < Lp.count; ++k) {
+                const WorkItem& n = h->items[Lp.first + k];
+                if (n.kind == K_COST) continue;
+                lean = lean && n.kind == want_p && n.tail_mode == mode && (n.tail_act == AVAE_ACT_RELU || n.tail_act == AVAE_ACT_SOFTPLUS)
+                            && (act < 0 || act == n.tail_act) && n.K > 0 && 2 * n.nz <= 64 && n.tail_kt >= 1 && n.tail_kt <= 2;
+                act = n.tail_act;
+            }
+            if (lean && mode == 1)
+                for (int k = 0; k < Lp.count; ++k) lean = lean && h->items[Lp.first + k].kind == K_FWD_HEAD && h->items[Lp.first + k].out1 != nullptr;
+            if (lean) { Lp.cfg = mode == 2 ? 10 : 11; Lp.lds = small_head_lds_bytes(); Lp.lean_act = act; }
+        }
         return true;
     };
     // conv-branch helper launches (one segment per conv modality)
@@ -1623,6 +1640,8 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         else if (L.type == 7) launch_gperm(L.gp, L.blocks, s);
         else if (L.type == 8) launch_rowsum(h->cfg.compute_dtype, L.rs, L.blocks, s);
         else if (L.type == 9) launch_sums(L.ra, L.blocks, s);
+        else if (L.cfg == 11) launch_small_head(h->cfg.compute_dtype, L.lean_act, L.args, L.grid_x, L.grid_y, L.lds, s, stamps, stamp_base + k);
+        else if (L.cfg == 10) launch_small_latb(h->cfg.compute_dtype, L.lean_act, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else if (L.cfg == 9) launch_small_loss(h->cfg.compute_dtype, L.args, L.grid_x, L.grid_y, L.lds, s, stamps, stamp_base + k);
         else if (L.cfg == 7) launch_small(h->cfg.compute_dtype, L.args, L.grid_x, L.grid_y, L.lds, s, stamps, stamp_base + k);
         else if (L.tn) launch_grouped_tn(h->cfg.compute_dtype, L.cfg, L.targs, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);

@@ -1125,7 +1125,7 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
                     for (int e = 0; e < 4; ++e) {
                         const int d = 4 * qs[k] + e;
                         if (d < nz)
-                            Zs[cs_idx<LDC>(rws[k], d)] = Cs[cs_idx<LDC>(rws[k], d)] + fexp(0.5f * Cs[cs_idx<LDC>(rws[k], nz + d)]) * ev[k][e];
+                            Zs[cs_idx<LDC>(rws[k], d)] = __builtin_fmaf(fexp(0.5f * Cs[cs_idx<LDC>(rws[k], nz + d)]), ev[k][e], Cs[cs_idx<LDC>(rws[k], d)]);
                     }
                 }
             }
@@ -1238,7 +1238,7 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
                             if (d < nz) {
                                 const float dz = Cs[cs_idx<LDC>(rws[k], d)];
                                 Zs[cs_idx<LDC>(rws[k], d)] = dz + gm[k][e];
-                                Zs[cs_idx<LDC>(rws[k], nz + d)] = dz * gf[k][e] + gl[k][e];
+                                Zs[cs_idx<LDC>(rws[k], nz + d)] = __builtin_fmaf(dz, gf[k][e], gl[k][e]);
                             }
                         }
                     }
@@ -1488,6 +1488,302 @@ void launch_small_loss(int compute_dtype, const LaunchArgs& args, int grid_x, in
     const dim3 grid(grid_x, grid_y), block(kThreads);
     if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_small_loss<__bf16>), grid, block, lds_bytes, s, args, stamps, launch_id);
     else AVAE_LAUNCH((k_small_loss<float>), grid, block, lds_bytes, s, args, stamps, launch_id);
+}
+
+// ---- the two head launches of the small nets on the lean frame (tile configurations 10 and 11): 32x64 tile, narrow result into an
+// LDS image in the K-tile layout the tail product reads its A fragments from (128-byte rows, chunk c of row r at c ^ ((r >> 1) & 7),
+// K tile kt at kt * 32 rows), tail product (WorkItem::tail_*) with kind and transfer function at compile time.
+constexpr int kHeadStage = (32 + 64) * kTileBytesK, kHeadImg = 2 * 32 * kTileBytesK;
+int small_head_lds_bytes() { return 4 * kHeadStage + kHeadImg + 64; }
+
+template <typename CT> __device__ __forceinline__ void img_put(unsigned char* img, int row, int d, float v) {
+    const int b = d * (int)sizeof(CT), bo = b & 127;
+    *reinterpret_cast<CT*>(img + (b >> 7) * (32 * kTileBytesK) + row * kTileBytesK + ((((bo >> 4) ^ ((row >> 1) & 7)) << 4) | (bo & 15))) = to_ct<CT>(v);
+}
+
+// bwd_dec1_latent + bwd_head: dz = dA . V1^T from the accumulators; dmu = dz + g0mu, dlv = dz * F + g0lv per lane (the latent item's
+// static gradients fetched ahead of the first tile); [dmu | dlv] -> dH and -> the image; tail = the heads' input gradient.  The step's
+// K_COST item rides in the launch.
+template <typename CT, int ACT>
+__global__ void __launch_bounds__(kThreads) k_small_latb(const LaunchArgs args, DevState* st, unsigned long long* stamps, int launch_id) {
+    constexpr int RING = 4, ES = (int)sizeof(CT), TSL = ES == 2 ? 2 : 4;
+    unsigned char* smem = avae_dyn_smem;
+    unsigned char* img = smem + RING * kHeadStage;
+    float* red = reinterpret_cast<float*>(img + kHeadImg);
+#ifdef AVAE_STAMPS
+    unsigned long long sv[kStampWords] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    AVAE_STAMP(0)
+    const int part = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const WorkItem w = args.items[blockIdx.y];
+    asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.aux2), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.tail_w), "s"(w.tail_out), "s"(w.tail_aux));
+    int t;
+    {
+        const int nt = w.tiles_m * w.tiles_n;
+        const int q = nt >> 3, r = nt & 7;
+        if (idx >= q + (part < r ? 1 : 0)) return;
+        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx;
+    }
+    if (w.kind == K_COST) {
+        cost_item<4>(w, st, red);
+        AVAE_STAMP(4)
+        AVAE_STAMP_FLUSH()
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tm = t / w.tiles_n, ts = t - tm * w.tiles_n;     // row block, tail slice
+    const int m0 = tm * 32;
+    const int nk = (w.K * ES) / kTileBytesK, nz = w.nz;
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    reinterpret_cast<f32x4*>(img)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};                 // the image's padding columns: zero (8 KiB = 2 x 256 x 16 B)
+    reinterpret_cast<f32x4*>(img)[tid + kThreads] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- operands of the epilogue and of the tail, fetched ahead of the first tile (older than every DMA: the counted waits stay exact)
+    const int orow = m0 + wr * 16 + fr;
+    const int lde = (nz + 3) & ~3;
+    f32x4 gm[2], gl[2], gf[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float* gr = reinterpret_cast<const float*>(w.aux2) + (size_t)min(orow, w.M - 1) * 3 * lde + min(wc * 32 + j * 16 + 4 * fq, lde - 4);
+        gm[j] = *reinterpret_cast<const f32x4*>(gr); gl[j] = *reinterpret_cast<const f32x4*>(gr + lde); gf[j] = *reinterpret_cast<const f32x4*>(gr + 2 * lde);
+    }
+    const int t_i = wave & 1, t_c0 = (2 * ts + (wave >> 1)) * 32, t_sl = 2 * w.tail_kt;
+    u32x4 tb[TSL][2];
+    typename Quad<CT>::raw ty[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned char* pw = reinterpret_cast<const unsigned char*>(w.tail_w) + (size_t)min(t_c0 + 16 * j + fr, w.tail_n - 1) * w.tail_ldw * ES + fq * 16;
+#pragma unroll
+        for (int sl = 0; sl < TSL; ++sl) if (TSL == 2 || sl < t_sl) tb[sl][j] = *reinterpret_cast<const u32x4*>(pw + 64 * sl);
+        ty[j] = *reinterpret_cast<const typename Quad<CT>::raw*>(reinterpret_cast<const CT*>(w.tail_aux) + (size_t)min(m0 + 16 * t_i + fr, w.M - 1) * w.tail_ldx
+                                                                   + min(t_c0 + 16 * j + 4 * fq, w.tail_ldx - 4));
+    }
+    // ---- K loop: three 1-KiB pieces per wave and stage (A rows 8 wave .., B rows 8 wave .. and 32 + 8 wave ..)
+    const int prow = wave * 8 + (lane >> 3), lc = ((lane & 7) ^ ((prow >> 1) & 7)) * 16;
+    const unsigned char* srcA = reinterpret_cast<const unsigned char*>(w.A) + (size_t)(m0 + prow) * w.lda * ES + lc;
+    const unsigned char* srcB = reinterpret_cast<const unsigned char*>(w.B) + (size_t)prow * w.ldb * ES + lc;
+    const size_t b32 = (size_t)32 * w.ldb * ES;
+#define AVAE_H_DMA(kt, buf)                                                                                             \
+    { __builtin_amdgcn_global_load_lds((gp_t)(srcA + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kHeadStage + wave * 1024), 16, 0, 0);       \
+      __builtin_amdgcn_global_load_lds((gp_t)(srcB + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kHeadStage + (4 + wave) * 1024), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((gp_t)(srcB + b32 + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kHeadStage + (8 + wave) * 1024), 16, 0, 0); }
+    AVAE_STAMP(1)
+    const int npro = nk < RING - 1 ? nk : RING - 1;
+    for (int p = 0; p < npro; ++p) AVAE_H_DMA(p, p)
+    const int sw0 = (fq ^ (fr >> 1)) * 16;
+    const int aoff = (wr * 16 + fr) * kTileBytesK, boff = (32 + wc * 32 + fr) * kTileBytesK;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (kt == 0) { AVAE_STAMP(2) }
+        const unsigned char* Sb = smem + buf * kHeadStage;
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(Sb + aoff + sw0);
+        const u32x4 b00 = *reinterpret_cast<const u32x4*>(Sb + boff + sw0), b01 = *reinterpret_cast<const u32x4*>(Sb + boff + 16 * kTileBytesK + sw0);
+        const int fill = buf == 0 ? RING - 1 : buf - 1;
+        if (kt + RING - 1 < nk) AVAE_H_DMA(kt + RING - 1, fill)
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(Sb + aoff + (sw0 ^ 64));
+        const u32x4 b10 = *reinterpret_cast<const u32x4*>(Sb + boff + (sw0 ^ 64)), b11 = *reinterpret_cast<const u32x4*>(Sb + boff + 16 * kTileBytesK + (sw0 ^ 64));
+        mma<CT>(b00, a0, acc[0]); mma<CT>(b01, a0, acc[1]);
+        mma<CT>(b10, a1, acc[0]); mma<CT>(b11, a1, acc[1]);
+        buf = buf + 1 == RING ? 0 : buf + 1;
+    }
+#undef AVAE_H_DMA
+    AVAE_STAMP(3)
+    // ---- dz -> (dmu, dlv): into the image (every slice) and into dH (slice 0)
+    {
+        CT* dH = reinterpret_cast<CT*>(w.out0) + (size_t)orow * w.ld0;
+        const bool store = ts == 0 && orow < w.M;
+        const int lrow = wr * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = wc * 32 + j * 16 + 4 * fq + e;
+                if (d < nz) {
+                    const float dz = acc[j][e];
+                    const float dmu = dz + gm[j][e], dlv = __builtin_fmaf(dz, gf[j][e], gl[j][e]);
+                    img_put<CT>(img, lrow, d, dmu);
+                    img_put<CT>(img, lrow, nz + d, dlv);
+                    if (store) { dH[d] = to_ct<CT>(dmu); dH[nz + d] = to_ct<CT>(dlv); }
+                }
+            }
+    }
+    lds_barrier();
+    AVAE_STAMP(5)
+    // ---- tail product: the heads' input gradient on [dmu | dlv]
+    {
+        const int arow = 16 * t_i + fr;
+        f32x4 tacc[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+        for (int sl = 0; sl < TSL; ++sl)
+            if (TSL == 2 || sl < t_sl) {
+                const u32x4 ta = *reinterpret_cast<const u32x4*>(img + (sl >> 1) * (32 * kTileBytesK) + arow * kTileBytesK + (((fq + 4 * (sl & 1)) ^ ((arow >> 1) & 7)) << 4));
+                mma<CT>(tb[sl][0], ta, tacc[0][0]);
+                mma<CT>(tb[sl][1], ta, tacc[0][1]);
+            }
+        regep_store<CT, 1, 2>(tacc, reinterpret_cast<CT*>(w.tail_out), w.tail_ldo, w.M, w.tail_n, m0 + arow, t_c0, lane,
+            [&](int, int j, int r, float v) { return v * act_bwd_t<ACT>(quad_elem<CT>(ty[j], r)); });
+    }
+    AVAE_STAMP(4)
+    AVAE_STAMP_FLUSH()
+}
+// fwd_head + fwd_dec1: [mu | lv] from the accumulators -> mulv (fp32, slice 0) and -> an fp32 tile in LDS (the ring is free by then);
+// z = mu + exp(lv / 2) * eps by one thread per (row, four latent dims) with eps fetched ahead of the first tile -> Z (slice 0) and
+// -> the image, with its constant-1 column; tail = the decoder's first layer.
+template <typename CT, int ACT>
+__global__ void __launch_bounds__(kThreads) k_small_head(const LaunchArgs args, unsigned long long* stamps, int launch_id) {
+    constexpr int RING = 4, ES = (int)sizeof(CT), TSL = ES == 2 ? 2 : 4, LDM = 68;
+    unsigned char* smem = avae_dyn_smem;
+    unsigned char* img = smem + RING * kHeadStage;
+    float* MV = reinterpret_cast<float*>(smem);                // [32][LDM] fp32, over the ring (after the loop's last barrier)
+#ifdef AVAE_STAMPS
+    unsigned long long sv[kStampWords] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    AVAE_STAMP(0)
+    const int part = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const WorkItem w = args.items[blockIdx.y];
+    asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out0), "s"(w.out1), "s"(w.aux0), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.tail_w), "s"(w.tail_out));
+    int t;
+    {
+        const int nt = w.tiles_m * w.tiles_n;
+        const int q = nt >> 3, r = nt & 7;
+        if (idx >= q + (part < r ? 1 : 0)) return;
+        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tm = t / w.tiles_n, ts = t - tm * w.tiles_n;
+    const int m0 = tm * 32;
+    const int nk = (w.K * ES) / kTileBytesK, nz = w.nz;
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    reinterpret_cast<f32x4*>(img)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    reinterpret_cast<f32x4*>(img)[tid + kThreads] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- fetched ahead of the first tile: eps of this thread's (row, four dims), the tail's weight fragments
+    const int zrow = tid >> 3, zg = tid & 7;
+    const f32x4 ev = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(w.aux0) + (size_t)min(m0 + zrow, w.M - 1) * w.ldx + min(4 * zg, w.ldx - 4));
+    const int t_i = wave & 1, t_c0 = (2 * ts + (wave >> 1)) * 32, t_sl = 2 * w.tail_kt;
+    u32x4 tb[TSL][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned char* pw = reinterpret_cast<const unsigned char*>(w.tail_w) + (size_t)min(t_c0 + 16 * j + fr, w.tail_n - 1) * w.tail_ldw * ES + fq * 16;
+#pragma unroll
+        for (int sl = 0; sl < TSL; ++sl) if (TSL == 2 || sl < t_sl) tb[sl][j] = *reinterpret_cast<const u32x4*>(pw + 64 * sl);
+    }
+    const int prow = wave * 8 + (lane >> 3), lc = ((lane & 7) ^ ((prow >> 1) & 7)) * 16;
+    const unsigned char* srcA = reinterpret_cast<const unsigned char*>(w.A) + (size_t)(m0 + prow) * w.lda * ES + lc;
+    const unsigned char* srcB = reinterpret_cast<const unsigned char*>(w.B) + (size_t)prow * w.ldb * ES + lc;
+    const size_t b32 = (size_t)32 * w.ldb * ES;
+#define AVAE_H_DMA(kt, buf)                                                                                             \
+    { __builtin_amdgcn_global_load_lds((gp_t)(srcA + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kHeadStage + wave * 1024), 16, 0, 0);       \
+      __builtin_amdgcn_global_load_lds((gp_t)(srcB + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kHeadStage + (4 + wave) * 1024), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((gp_t)(srcB + b32 + (size_t)(kt) * kTileBytesK), (lp_t)(smem + (buf) * kHeadStage + (8 + wave) * 1024), 16, 0, 0); }
+    AVAE_STAMP(1)
+    const int npro = nk < RING - 1 ? nk : RING - 1;
+    for (int p = 0; p < npro; ++p) AVAE_H_DMA(p, p)
+    const int sw0 = (fq ^ (fr >> 1)) * 16;
+    const int aoff = (wr * 16 + fr) * kTileBytesK, boff = (32 + wc * 32 + fr) * kTileBytesK;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (kt == 0) { AVAE_STAMP(2) }
+        const unsigned char* Sb = smem + buf * kHeadStage;
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(Sb + aoff + sw0);
+        const u32x4 b00 = *reinterpret_cast<const u32x4*>(Sb + boff + sw0), b01 = *reinterpret_cast<const u32x4*>(Sb + boff + 16 * kTileBytesK + sw0);
+        const int fill = buf == 0 ? RING - 1 : buf - 1;
+        if (kt + RING - 1 < nk) AVAE_H_DMA(kt + RING - 1, fill)
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(Sb + aoff + (sw0 ^ 64));
+        const u32x4 b10 = *reinterpret_cast<const u32x4*>(Sb + boff + (sw0 ^ 64)), b11 = *reinterpret_cast<const u32x4*>(Sb + boff + 16 * kTileBytesK + (sw0 ^ 64));
+        mma<CT>(b00, a0, acc[0]); mma<CT>(b01, a0, acc[1]);
+        mma<CT>(b10, a1, acc[0]); mma<CT>(b11, a1, acc[1]);
+        buf = buf + 1 == RING ? 0 : buf + 1;
+    }
+#undef AVAE_H_DMA
+    lds_barrier();                                              // every wave is done with the ring: MV may overwrite it
+    AVAE_STAMP(3)
+    // ---- [mu | lv]: into MV (every slice) and into mulv (slice 0), columns [0, nz) = mu, [nz, 2 nz) = log sigma^2 (vae_assoc.py:217-221)
+    {
+        const int orow = m0 + wr * 16 + fr, lrow = wr * 16 + fr;
+        float* mulv = reinterpret_cast<float*>(w.out0) + (size_t)orow * w.ld0;
+        const bool store = ts == 0 && orow < w.M;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c0 = wc * 32 + j * 16 + 4 * fq;
+            *reinterpret_cast<f32x4*>(MV + lrow * LDM + c0) = acc[j];
+            if (store) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c0 + e < 2 * nz) mulv[c0 + e] = acc[j][e];
+            }
+        }
+    }
+    lds_barrier();
+    AVAE_STAMP(5)
+    // ---- z = mu + sqrt(exp(lv)) * eps (:102-103): thread (row, four dims) -> Z (slice 0) and the image; [z | 1] is the tail's operand
+    {
+        CT* Z = reinterpret_cast<CT*>(w.out1) + (size_t)(m0 + zrow) * w.ld1;
+        const bool store = ts == 0 && m0 + zrow < w.M;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int d = 4 * zg + e;
+            if (d < nz) {
+                const float z = __builtin_fmaf(fexp(0.5f * MV[zrow * LDM + nz + d]), ev[e], MV[zrow * LDM + d]);
+                img_put<CT>(img, zrow, d, z);
+                if (store) Z[d] = to_ct<CT>(z);
+            }
+        }
+        if (tid < 32) img_put<CT>(img, tid, nz, 1.0f);         // the constant-1 (bias) column of [z | 1]
+    }
+    lds_barrier();
+    AVAE_STAMP_EP(6)
+    // ---- tail product: the decoder's first layer on [z | 1]
+    {
+        const int arow = 16 * t_i + fr;
+        f32x4 tacc[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+        for (int sl = 0; sl < TSL; ++sl)
+            if (TSL == 2 || sl < t_sl) {
+                const u32x4 ta = *reinterpret_cast<const u32x4*>(img + (sl >> 1) * (32 * kTileBytesK) + arow * kTileBytesK + (((fq + 4 * (sl & 1)) ^ ((arow >> 1) & 7)) << 4));
+                mma<CT>(tb[sl][0], ta, tacc[0][0]);
+                mma<CT>(tb[sl][1], ta, tacc[0][1]);
+            }
+        regep_store<CT, 1, 2>(tacc, reinterpret_cast<CT*>(w.tail_out), w.tail_ldo, w.M, w.tail_n, m0 + arow, t_c0, lane,
+            [&](int, int, int, float v) { return act_fwd_t<ACT>(v); });
+    }
+    AVAE_STAMP(4)
+    AVAE_STAMP_FLUSH()
+}
+void launch_small_head(int compute_dtype, int act, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s,
+                       unsigned long long* stamps, int launch_id) {
+    const dim3 grid(grid_x, grid_y), block(kThreads);
+    if (compute_dtype == AVAE_BF16) {
+        if (act == AVAE_ACT_RELU) AVAE_LAUNCH((k_small_head<__bf16, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, stamps, launch_id);
+        else AVAE_LAUNCH((k_small_head<__bf16, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, stamps, launch_id);
+    } else {
+        if (act == AVAE_ACT_RELU) AVAE_LAUNCH((k_small_head<float, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, stamps, launch_id);
+        else AVAE_LAUNCH((k_small_head<float, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, stamps, launch_id);
+    }
+}
+void launch_small_latb(int compute_dtype, int act, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, DevState* st, hipStream_t s,
+                       unsigned long long* stamps, int launch_id) {
+    const dim3 grid(grid_x, grid_y), block(kThreads);
+    if (compute_dtype == AVAE_BF16) {
+        if (act == AVAE_ACT_RELU) AVAE_LAUNCH((k_small_latb<__bf16, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, st, stamps, launch_id);
+        else AVAE_LAUNCH((k_small_latb<__bf16, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, st, stamps, launch_id);
+    } else {
+        if (act == AVAE_ACT_RELU) AVAE_LAUNCH((k_small_latb<float, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, st, stamps, launch_id);
+        else AVAE_LAUNCH((k_small_latb<float, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, st, stamps, launch_id);
+    }
 }
 
 template <typename CT, int KIND>
