@@ -1539,26 +1539,9 @@ __global__ void __launch_bounds__(kThreads) k_small_latb(const LaunchArgs args, 
     typedef __attribute__((address_space(3))) void* lp_t;
     reinterpret_cast<f32x4*>(img)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};                 // the image's padding columns: zero (8 KiB = 2 x 256 x 16 B)
     reinterpret_cast<f32x4*>(img)[tid + kThreads] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // ---- operands of the epilogue and of the tail, fetched ahead of the first tile (older than every DMA: the counted waits stay exact)
     const int orow = m0 + wr * 16 + fr;
     const int lde = (nz + 3) & ~3;
-    f32x4 gm[2], gl[2], gf[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float* gr = reinterpret_cast<const float*>(w.aux2) + (size_t)min(orow, w.M - 1) * 3 * lde + min(wc * 32 + j * 16 + 4 * fq, lde - 4);
-        gm[j] = *reinterpret_cast<const f32x4*>(gr); gl[j] = *reinterpret_cast<const f32x4*>(gr + lde); gf[j] = *reinterpret_cast<const f32x4*>(gr + 2 * lde);
-    }
     const int t_i = wave & 1, t_c0 = (2 * ts + (wave >> 1)) * 32, t_sl = 2 * w.tail_kt;
-    u32x4 tb[TSL][2];
-    typename Quad<CT>::raw ty[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const unsigned char* pw = reinterpret_cast<const unsigned char*>(w.tail_w) + (size_t)min(t_c0 + 16 * j + fr, w.tail_n - 1) * w.tail_ldw * ES + fq * 16;
-#pragma unroll
-        for (int sl = 0; sl < TSL; ++sl) if (TSL == 2 || sl < t_sl) tb[sl][j] = *reinterpret_cast<const u32x4*>(pw + 64 * sl);
-        ty[j] = *reinterpret_cast<const typename Quad<CT>::raw*>(reinterpret_cast<const CT*>(w.tail_aux) + (size_t)min(m0 + 16 * t_i + fr, w.M - 1) * w.tail_ldx
-                                                                   + min(t_c0 + 16 * j + 4 * fq, w.tail_ldx - 4));
-    }
     // ---- K loop: three 1-KiB pieces per wave and stage (A rows 8 wave .., B rows 8 wave .. and 32 + 8 wave ..)
     const int prow = wave * 8 + (lane >> 3), lc = ((lane & 7) ^ ((prow >> 1) & 7)) * 16;
     const unsigned char* srcA = reinterpret_cast<const unsigned char*>(w.A) + (size_t)(m0 + prow) * w.lda * ES + lc;
@@ -1571,15 +1554,43 @@ __global__ void __launch_bounds__(kThreads) k_small_latb(const LaunchArgs args, 
     AVAE_STAMP(1)
     const int npro = nk < RING - 1 ? nk : RING - 1;
     for (int p = 0; p < npro; ++p) AVAE_H_DMA(p, p)
+    // ---- operands of the epilogue and of the tail: EXACTLY kExtra loads per wave, issued BEHIND the prologue's tiles so that the first
+    // tile does not queue behind them; the tiles of the prologue are older, so while one of them is awaited these loads may stay in
+    // flight and are counted in its wait (vmcnt retires in issue order).  Always TSL slabs per column block: the count is static.
+    constexpr int kExtra = 6 + 2 * TSL + 2;
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);       // (neither the compiler nor the scheduler may move them ahead of the tiles)
+    f32x4 gm[2], gl[2], gf[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float* gr = reinterpret_cast<const float*>(w.aux2) + (size_t)min(orow, w.M - 1) * 3 * lde + min(wc * 32 + j * 16 + 4 * fq, lde - 4);
+        gm[j] = *reinterpret_cast<const f32x4*>(gr); gl[j] = *reinterpret_cast<const f32x4*>(gr + lde); gf[j] = *reinterpret_cast<const f32x4*>(gr + 2 * lde);
+    }
+    u32x4 tb[TSL][2];
+    typename Quad<CT>::raw ty[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned char* pw = reinterpret_cast<const unsigned char*>(w.tail_w) + (size_t)min(t_c0 + 16 * j + fr, w.tail_n - 1) * w.tail_ldw * ES + fq * 16;
+#pragma unroll
+        for (int sl = 0; sl < TSL; ++sl) tb[sl][j] = *reinterpret_cast<const u32x4*>(pw + (sl < t_sl ? 64 * sl : 0));
+        ty[j] = *reinterpret_cast<const typename Quad<CT>::raw*>(reinterpret_cast<const CT*>(w.tail_aux) + (size_t)min(m0 + 16 * t_i + fr, w.M - 1) * w.tail_ldx
+                                                                   + min(t_c0 + 16 * j + 4 * fq, w.tail_ldx - 4));
+    }
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
     const int sw0 = (fq ^ (fr >> 1)) * 16;
     const int aoff = (wr * 16 + fr) * kTileBytesK, boff = (32 + wc * 32 + fr) * kTileBytesK;
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const int rem = nk - 1 - kt;
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt < npro) {             // a tile of the prologue: the extra loads are younger than it
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 + kExtra) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + kExtra) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kExtra) : "memory");
+        } else {
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         asm volatile("s_barrier" ::: "memory");
         if (kt == 0) { AVAE_STAMP(2) }
         const unsigned char* Sb = smem + buf * kHeadStage;
