@@ -21,7 +21,7 @@ def main():
     trace, order_file = sys.argv[1], sys.argv[2]
     oj = json.load(open(order_file))                      # {"order": [...]} or a bench.py JSON line (its "launch_order")
     names = oj["order"] if "order" in oj else oj["launch_order"]          # launches of one step in order, ending with "adam"
-    rows = [r for r in csv.DictReader(open(trace)) if any(k in r["Kernel_Name"] for k in ("k_prep", "k_grouped", "k_gather", "k_col2im", "k_adam", "k_thin", "k_wadj", "k_gperm", "k_rowsum",
+    rows = [r for r in csv.DictReader(open(trace)) if any(k in r["Kernel_Name"] for k in ("k_prep", "k_grouped", "k_small", "k_gather", "k_col2im", "k_adam", "k_thin", "k_wadj", "k_gperm", "k_rowsum",
                                                                                       "k_colsum", "k_reduce", "k_sums"))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))            # the CSV is not in execution order
     # a step ends with k_adam; the staging kernel k_prep runs once per step or once per replay of 16 / 4 steps

@@ -32,7 +32,7 @@ def per_position(counter, sub):
             continue
         if pos < 0:
             continue
-        if "k_grouped" in n or "k_adam" in n:
+        if "k_grouped" in n or "k_small" in n or "k_adam" in n:
             pos += 1
             if steps > 12:
                 seq[pos].append(float(r["Counter_Value"]))
