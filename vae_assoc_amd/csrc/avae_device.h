@@ -306,6 +306,15 @@ struct ServeArgs {               // the per-call staging launch: z -> Z of every
     int blocks_per_mod;
 };
 void launch_serve(int compute_dtype, const ServeArgs& a, const ServeSlot& call, int n_blocks, hipStream_t s);
+// k_serve_in: the staging launch that also runs the decoder's first layer (small nets)
+struct ServeInMod { const void* w; void* out; int n, ldw, ldo, kt, act, slices; };   // first decoder layer of one modality: weight shadow [n][ldw], output [bucket][ldo]
+struct ServeInArgs {
+    ServeSlot call;                // this call's pointers and row count
+    ServeSlot* slot;               // where the graph's output launch reads them
+    int n_mod, nz, bucket, tiles_m;
+    ServeInMod mod[kMaxMod];
+};
+void launch_serve_in(int compute_dtype, const ServeInArgs& a, int grid_x, hipStream_t s);
 
 void launch_gather(int compute_dtype, const GatherArgs& a, int n_blocks, hipStream_t s);
 void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStream_t s);

@@ -213,7 +213,8 @@ struct avae_handle {
     // serving (avae_generate): per row bucket one staging launch per call + one captured graph of [grouped decoder launches of all
     // modalities, slot-indirect output move]
     struct Serve { int bucket = 0; std::vector<WorkItem> items; std::vector<Launch> launches; hipGraphExec_t graph = nullptr; ServeArgs in;
-                   Launch in_launch; bool fused_in = false; };
+                   Launch in_launch; bool fused_in = false;
+                   ServeInArgs in_lean; int in_lean_grid = 0; bool lean_in = false; };
     std::vector<Serve> serve;
     size_t off_slot = 0;
 
@@ -789,6 +790,9 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
             for (int i = first; i < first + count; ++i)
                 lean = lean && items[i].kind == k0 && items[i].act == a0 && !items[i].bias_ep && items[i].K > 0;
             if (lean && (k0 == K_FWD_HIDDEN || k0 == K_DGRAD_HIDDEN) && (a0 == AVAE_ACT_RELU || a0 == AVAE_ACT_SOFTPLUS)) L.cfg = 7;
+            bool store = true;                                    // the inference / serving output launch: k_small's third kind
+            for (int i = first; i < first + count; ++i) store = store && items[i].kind == K_FWD_OUT_STORE && !items[i].bias_ep && items[i].K > 0;
+            if (store) L.cfg = 7;
             bool loss = false, only_loss = true;                  // the output + loss launch (with the latent item riding in it): k_small_loss
             for (int i = first; i < first + count; ++i) {
                 loss = loss || items[i].kind == K_FWD_OUT_LOSS;
@@ -2123,6 +2127,21 @@ avae_handle::Serve& serve_plan(avae_handle* h, int bucket) {
             sv.in_launch = finish_launch(h, sv.items, first, (int)sv.items.size() - first, "serve_in+serve_dec1", &slot);
             if (sv.in_launch.cfg != 3) fits = false;
         }
+        if (fits && !std::getenv("AVAE_NO_LEAN")) {            // the same launch as a kernel of its own with a small argument block (k_serve_in)
+            ServeInArgs& ia = sv.in_lean;
+            std::memset(&ia, 0, sizeof(ia));
+            ia.slot = h->at<ServeSlot>(h->off_slot); ia.n_mod = h->M; ia.nz = h->nz; ia.bucket = bucket; ia.tiles_m = (bucket + 31) / 32;
+            int max_slices = 1;
+            for (int m = 0; m < h->M; ++m) {
+                const WorkItem& w = sv.items[first + m];
+                ServeInMod& md = ia.mod[m];
+                md.w = w.tail_w; md.out = w.tail_out; md.n = w.tail_n; md.ldw = w.tail_ldw; md.ldo = w.tail_ldo; md.kt = w.tail_kt; md.act = w.tail_act;
+                md.slices = (w.tail_n + 63) / 64;
+                max_slices = std::max(max_slices, md.slices);
+            }
+            sv.in_lean_grid = ia.tiles_m * max_slices;
+            sv.lean_in = true;
+        }
         if (!fits) sv.items.resize(first);
         sv.fused_in = fits;
     }
@@ -2573,7 +2592,10 @@ int avae_generate(avae_handle* h, const float* z_dev, int32_t rows, float* const
             std::memset(&sl, 0, sizeof(sl));
             sl.z = z_dev + (size_t)r0 * h->nz; sl.rows = n;
             for (int m = 0; m < h->M; ++m) sl.out[m] = xhat_dev[m] + (size_t)r0 * h->mods[m].n_in;
-            if (sv.fused_in) {           // the staging launch also runs the decoder's first layer: its items carry the call by value
+            if (sv.fused_in && sv.lean_in) {
+                sv.in_lean.call = sl;
+                launch_serve_in(h->cfg.compute_dtype, sv.in_lean, sv.in_lean_grid, s); LAUNCH_OK("serve_in+serve_dec1");
+            } else if (sv.fused_in) {    // the staging launch also runs the decoder's first layer: its items carry the call by value
                 Launch& L = sv.in_launch;
                 for (int m = 0; m < h->M; ++m) {
                     WorkItem& w = L.args.items[m];

@@ -1364,7 +1364,21 @@ __global__ void __launch_bounds__(kThreads) k_small(const LaunchArgs args, unsig
     }
 #undef AVAE_S_DMA
     AVAE_STAMP(3)
-    if (orow < w.M && ocol < w.N) {
+    if constexpr (KIND == 2) {       // K_FWD_OUT_STORE (inference): x_hat = sigmoid(logits) | logits as fp32, to the plan's buffer or, when serving,
+        float v[4];                  // straight into the caller's dense [rows][N] of modality n_mod through the slot (avae_generate)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = w.binary ? sigmoidf_(acc[e]) : acc[e];
+        if (w.aux2) {
+            const ServeSlot* sp = reinterpret_cast<const ServeSlot*>(w.aux2);
+            float* dst = sp->out[w.n_mod] + (size_t)orow * w.N + ocol;
+            if (orow < sp->rows) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (ocol + e < w.N) dst[e] = v[e];
+            }
+        } else if (orow < w.M && ocol < w.N) {
+            store_row<float>(reinterpret_cast<float*>(w.out0) + (size_t)orow * w.ld0 + ocol, v, w.N - ocol);
+        }
+    } else if (orow < w.M && ocol < w.N) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1807,6 +1821,12 @@ static void launch_small_act(int act, const LaunchArgs& args, dim3 grid, int lds
 void launch_small(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id) {
     const dim3 grid(grid_x, grid_y);
     const int kind = args.items[0].kind == K_DGRAD_HIDDEN ? 1 : 0, act = args.items[0].act;
+    if (args.items[0].kind == K_FWD_OUT_STORE) {
+        const dim3 block(kThreads);
+        if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_small<__bf16, 2, AVAE_ACT_IDENTITY>), grid, block, lds_bytes, s, args, stamps, launch_id);
+        else AVAE_LAUNCH((k_small<float, 2, AVAE_ACT_IDENTITY>), grid, block, lds_bytes, s, args, stamps, launch_id);
+        return;
+    }
     if (compute_dtype == AVAE_BF16) { if (kind) launch_small_act<__bf16, 1>(act, args, grid, lds_bytes, s, stamps, launch_id); else launch_small_act<__bf16, 0>(act, args, grid, lds_bytes, s, stamps, launch_id); }
     else { if (kind) launch_small_act<float, 1>(act, args, grid, lds_bytes, s, stamps, launch_id); else launch_small_act<float, 0>(act, args, grid, lds_bytes, s, stamps, launch_id); }
 }
@@ -2536,6 +2556,61 @@ __global__ void __launch_bounds__(kThreads) k_serve(ServeArgs a, ServeSlot call)
         reinterpret_cast<CT*>(a.Z[m])[(size_t)r * a.ldz[m] + c] = to_ct<CT>(v);
     }
 }
+// The per-call launch of avae_generate for the small nets, lean: no K loop at all -- the call's fp32 z rows go into the tail's LDS
+// image (rows beyond the call's zero, constant-1 column included), the decoder's first layer of modality blockIdx.y is the tail
+// product (slice = 64 output columns per workgroup), workgroup (0, 0) publishes the call's slot.  A 300-byte argument block instead of
+// the grouped kernel's 3.4 KB: the host side of a call is the launch of this kernel + one graph replay.
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_serve_in(ServeInArgs a) {
+    constexpr int ES = (int)sizeof(CT), TSL = ES == 2 ? 2 : 4;
+    __shared__ __attribute__((aligned(16))) unsigned char img[kHeadImg];
+    const ServeInMod md = a.mod[blockIdx.y];
+    const int tm = blockIdx.x / md.slices, ts = blockIdx.x - tm * md.slices;
+    if (tm >= a.tiles_m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int m0 = tm * 32, nz = a.nz;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.slot = a.call;
+    const int t_i = wave & 1, t_c0 = (2 * ts + (wave >> 1)) * 32, t_sl = 2 * md.kt;
+    u32x4 tb[TSL][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned char* pw = reinterpret_cast<const unsigned char*>(md.w) + (size_t)min(t_c0 + 16 * j + fr, md.n - 1) * md.ldw * ES + fq * 16;
+#pragma unroll
+        for (int sl = 0; sl < TSL; ++sl) if (TSL == 2 || sl < t_sl) tb[sl][j] = *reinterpret_cast<const u32x4*>(pw + 64 * sl);
+    }
+    reinterpret_cast<f32x4*>(img)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    reinterpret_cast<f32x4*>(img)[tid + kThreads] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lds_barrier();
+    {
+        const int zrow = tid >> 3, zg = tid & 7;
+        if (m0 + zrow < a.call.rows) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = 4 * zg + e;
+                if (d < nz) img_put<CT>(img, zrow, d, a.call.z[(size_t)(m0 + zrow) * nz + d]);
+            }
+        }
+        if (tid < 32) img_put<CT>(img, tid, nz, 1.0f);
+    }
+    lds_barrier();
+    const int arow = 16 * t_i + fr;
+    f32x4 tacc[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+    for (int sl = 0; sl < TSL; ++sl)
+        if (TSL == 2 || sl < t_sl) {
+            const u32x4 ta = *reinterpret_cast<const u32x4*>(img + (sl >> 1) * (32 * kTileBytesK) + arow * kTileBytesK + (((fq + 4 * (sl & 1)) ^ ((arow >> 1) & 7)) << 4));
+            mma<CT>(tb[sl][0], ta, tacc[0][0]);
+            mma<CT>(tb[sl][1], ta, tacc[0][1]);
+        }
+    AVAE_ACT_DISPATCH(md.act, (regep_store<CT, 1, 2>(tacc, reinterpret_cast<CT*>(md.out), md.ldo, a.bucket, md.n, m0 + arow, t_c0, lane,
+        [&](int, int, int, float v) { return act_fwd_t<ACT>(v); })))
+}
+void launch_serve_in(int compute_dtype, const ServeInArgs& a, int grid_x, hipStream_t s) {
+    const dim3 grid(grid_x, a.n_mod), block(kThreads);
+    if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_serve_in<__bf16>), grid, block, 0, s, a);
+    else AVAE_LAUNCH((k_serve_in<float>), grid, block, 0, s, a);
+}
+
 void launch_serve(int compute_dtype, const ServeArgs& a, const ServeSlot& call, int n_blocks, hipStream_t s) {
     if (n_blocks <= 0) return;
     if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_serve<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a, call);
