@@ -467,7 +467,7 @@ def test_lean_small_tile_kernel(V, monkeypatch, dtype):
     register epilogue); AVAE_NO_LEAN=1 keeps them on k_grouped's 32x32 instance.  Both pass the oracle parity and agree bitwise
     (same tiles, same K order, same rounding points); relu and softplus, a partial last row tile."""
     archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
-    for act in ("relu", "softplus"):
+    for act in ("relu", "softplus", "tanh"):
         monkeypatch.delenv("AVAE_NO_LEAN", raising=False)
         on, _e, X, eps = check_step_parity(V, archs, [True, False], [50.0, 1.0], 8.0, act, 100, dtype, steps=1)
         monkeypatch.setenv("AVAE_NO_LEAN", "1")

@@ -784,12 +784,12 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         bool head = false;
         for (int i = first; i < first + count; ++i) head = head || items[i].kind == K_FWD_HEAD || items[i].kind == K_DGRAD_LATENT || items[i].kind == K_SERVE_Z;
         if (L.cfg == 3 && !head && !std::getenv("AVAE_NO_32x32")) L.cfg = 5;      // no kind that needs 2*n_z columns in one tile
-        if (L.cfg == 5 && !std::getenv("AVAE_NO_LEAN")) {       // the chain's two kinds, one of them per launch, relu / softplus: the lean kernel (k_small)
+        if (L.cfg == 5 && !std::getenv("AVAE_NO_LEAN")) {       // the chain's two kinds, one of them (and one transfer function) per launch: the lean kernel (k_small)
             bool lean = true;
             const int k0 = items[first].kind, a0 = items[first].act;
             for (int i = first; i < first + count; ++i)
                 lean = lean && items[i].kind == k0 && items[i].act == a0 && !items[i].bias_ep && items[i].K > 0;
-            if (lean && (k0 == K_FWD_HIDDEN || k0 == K_DGRAD_HIDDEN) && (a0 == AVAE_ACT_RELU || a0 == AVAE_ACT_SOFTPLUS)) L.cfg = 7;
+            if (lean && (k0 == K_FWD_HIDDEN || k0 == K_DGRAD_HIDDEN)) L.cfg = 7;
             bool store = true;                                    // the inference / serving output launch: k_small's third kind
             for (int i = first; i < first + count; ++i) store = store && items[i].kind == K_FWD_OUT_STORE && !items[i].bias_ep && items[i].K > 0;
             if (store) L.cfg = 7;
@@ -994,7 +994,7 @@ void build_training_plan(avae_handle* h) {
         Lp.grid_x = (max_tiles + 7) & ~7; Lp.blocks = Lp.grid_x * Lp.grid_y; Lp.args.grid_x = Lp.grid_x;
         Lp.name += "+" + Lc.name;
         ls.pop_back();
-        // the lean frame for the fused head launches (k_small_latb): every GEMM item of the kind, relu / softplus, its narrow result and
+        // the lean frame for the fused head launches (k_small_latb): every GEMM item of the kind, one transfer function, its narrow result and
         // the consumer's K within the 8-KiB image
         if (!std::getenv("AVAE_NO_LEAN") && !std::getenv("AVAE_NO_LEAN_HEAD")) {
             bool lean = true;
@@ -1002,7 +1002,7 @@ void build_training_plan(avae_handle* h) {
             for (int k = 0; k < Lp.count; ++k) {
                 const WorkItem& n = h->items[Lp.first + k];
                 if (n.kind == K_COST) continue;
-                lean = lean && n.kind == want_p && n.tail_mode == mode && (n.tail_act == AVAE_ACT_RELU || n.tail_act == AVAE_ACT_SOFTPLUS)
+                lean = lean && n.kind == want_p && n.tail_mode == mode
                             && (act < 0 || act == n.tail_act) && n.K > 0 && 2 * n.nz <= 64 && n.tail_kt >= 1 && n.tail_kt <= 2;
                 act = n.tail_act;
             }

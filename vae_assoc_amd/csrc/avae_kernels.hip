@@ -1788,36 +1788,70 @@ __global__ void __launch_bounds__(kThreads) k_small_head(const LaunchArgs args, 
     AVAE_STAMP(4)
     AVAE_STAMP_FLUSH()
 }
+// every transfer function of the ABI has its instance of the lean kernels (the choice is made per launch on the host)
 void launch_small_head(int compute_dtype, int act, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s,
                        unsigned long long* stamps, int launch_id) {
     const dim3 grid(grid_x, grid_y), block(kThreads);
+#define K_HEAD_B(A) k_small_head<__bf16, A>
+#define K_HEAD_F(A) k_small_head<float, A>
     if (compute_dtype == AVAE_BF16) {
-        if (act == AVAE_ACT_RELU) AVAE_LAUNCH((k_small_head<__bf16, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, stamps, launch_id);
-        else AVAE_LAUNCH((k_small_head<__bf16, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, stamps, launch_id);
+        switch (act) {
+            case AVAE_ACT_RELU: AVAE_LAUNCH((K_HEAD_B(AVAE_ACT_RELU)), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+            case AVAE_ACT_SOFTPLUS: AVAE_LAUNCH((K_HEAD_B(AVAE_ACT_SOFTPLUS)), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+            case AVAE_ACT_SIGMOID: AVAE_LAUNCH((K_HEAD_B(AVAE_ACT_SIGMOID)), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+            case AVAE_ACT_TANH: AVAE_LAUNCH((K_HEAD_B(AVAE_ACT_TANH)), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+            default: AVAE_LAUNCH((K_HEAD_B(AVAE_ACT_IDENTITY)), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+        }
     } else {
-        if (act == AVAE_ACT_RELU) AVAE_LAUNCH((k_small_head<float, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, stamps, launch_id);
-        else AVAE_LAUNCH((k_small_head<float, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, stamps, launch_id);
+        switch (act) {
+            case AVAE_ACT_RELU: AVAE_LAUNCH((K_HEAD_F(AVAE_ACT_RELU)), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+            case AVAE_ACT_SOFTPLUS: AVAE_LAUNCH((K_HEAD_F(AVAE_ACT_SOFTPLUS)), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+            case AVAE_ACT_SIGMOID: AVAE_LAUNCH((K_HEAD_F(AVAE_ACT_SIGMOID)), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+            case AVAE_ACT_TANH: AVAE_LAUNCH((K_HEAD_F(AVAE_ACT_TANH)), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+            default: AVAE_LAUNCH((K_HEAD_F(AVAE_ACT_IDENTITY)), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+        }
     }
+#undef K_HEAD_B
+#undef K_HEAD_F
 }
 void launch_small_latb(int compute_dtype, int act, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, DevState* st, hipStream_t s,
                        unsigned long long* stamps, int launch_id) {
     const dim3 grid(grid_x, grid_y), block(kThreads);
+#define K_LATB_B(A) k_small_latb<__bf16, A>
+#define K_LATB_F(A) k_small_latb<float, A>
     if (compute_dtype == AVAE_BF16) {
-        if (act == AVAE_ACT_RELU) AVAE_LAUNCH((k_small_latb<__bf16, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, st, stamps, launch_id);
-        else AVAE_LAUNCH((k_small_latb<__bf16, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, st, stamps, launch_id);
+        switch (act) {
+            case AVAE_ACT_RELU: AVAE_LAUNCH((K_LATB_B(AVAE_ACT_RELU)), grid, block, lds_bytes, s, args, st, stamps, launch_id); break;
+            case AVAE_ACT_SOFTPLUS: AVAE_LAUNCH((K_LATB_B(AVAE_ACT_SOFTPLUS)), grid, block, lds_bytes, s, args, st, stamps, launch_id); break;
+            case AVAE_ACT_SIGMOID: AVAE_LAUNCH((K_LATB_B(AVAE_ACT_SIGMOID)), grid, block, lds_bytes, s, args, st, stamps, launch_id); break;
+            case AVAE_ACT_TANH: AVAE_LAUNCH((K_LATB_B(AVAE_ACT_TANH)), grid, block, lds_bytes, s, args, st, stamps, launch_id); break;
+            default: AVAE_LAUNCH((K_LATB_B(AVAE_ACT_IDENTITY)), grid, block, lds_bytes, s, args, st, stamps, launch_id); break;
+        }
     } else {
-        if (act == AVAE_ACT_RELU) AVAE_LAUNCH((k_small_latb<float, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, st, stamps, launch_id);
-        else AVAE_LAUNCH((k_small_latb<float, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, st, stamps, launch_id);
+        switch (act) {
+            case AVAE_ACT_RELU: AVAE_LAUNCH((K_LATB_F(AVAE_ACT_RELU)), grid, block, lds_bytes, s, args, st, stamps, launch_id); break;
+            case AVAE_ACT_SOFTPLUS: AVAE_LAUNCH((K_LATB_F(AVAE_ACT_SOFTPLUS)), grid, block, lds_bytes, s, args, st, stamps, launch_id); break;
+            case AVAE_ACT_SIGMOID: AVAE_LAUNCH((K_LATB_F(AVAE_ACT_SIGMOID)), grid, block, lds_bytes, s, args, st, stamps, launch_id); break;
+            case AVAE_ACT_TANH: AVAE_LAUNCH((K_LATB_F(AVAE_ACT_TANH)), grid, block, lds_bytes, s, args, st, stamps, launch_id); break;
+            default: AVAE_LAUNCH((K_LATB_F(AVAE_ACT_IDENTITY)), grid, block, lds_bytes, s, args, st, stamps, launch_id); break;
+        }
     }
+#undef K_LATB_B
+#undef K_LATB_F
 }
 
 template <typename CT, int KIND>
 static void launch_small_act(int act, const LaunchArgs& args, dim3 grid, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id) {
     const dim3 block(kThreads);
-    if (act == AVAE_ACT_RELU) AVAE_LAUNCH((k_small<CT, KIND, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, stamps, launch_id);
-    else AVAE_LAUNCH((k_small<CT, KIND, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, stamps, launch_id);
+    switch (act) {
+        case AVAE_ACT_RELU: AVAE_LAUNCH((k_small<CT, KIND, AVAE_ACT_RELU>), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+        case AVAE_ACT_SOFTPLUS: AVAE_LAUNCH((k_small<CT, KIND, AVAE_ACT_SOFTPLUS>), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+        case AVAE_ACT_SIGMOID: AVAE_LAUNCH((k_small<CT, KIND, AVAE_ACT_SIGMOID>), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+        case AVAE_ACT_TANH: AVAE_LAUNCH((k_small<CT, KIND, AVAE_ACT_TANH>), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+        default: AVAE_LAUNCH((k_small<CT, KIND, AVAE_ACT_IDENTITY>), grid, block, lds_bytes, s, args, stamps, launch_id); break;
+    }
 }
-// tile_cfg 7 (host: finish_launch): every item of the launch is of ONE of the two kinds, with relu or softplus
+// tile_cfg 7 (host: finish_launch): every item of the launch is of ONE kind (hidden forward, hidden dgrad or output store) and one transfer function
 void launch_small(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id) {
     const dim3 grid(grid_x, grid_y);
     const int kind = args.items[0].kind == K_DGRAD_HIDDEN ? 1 : 0, act = args.items[0].act;
