@@ -24,14 +24,15 @@ def main():
     rows = [r for r in csv.DictReader(open(trace)) if any(k in r["Kernel_Name"] for k in ("k_prep", "k_grouped", "k_small", "k_gather", "k_col2im", "k_adam", "k_thin", "k_wadj", "k_gperm", "k_rowsum",
                                                                                       "k_colsum", "k_reduce", "k_sums"))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))            # the CSV is not in execution order
-    # a step ends with k_adam; the staging kernel k_prep runs once per step or once per replay of 16 / 4 steps
+    # a step ends with k_adam (or with the weight-gradient launch that carries it); the staging kernel k_prep runs once per step or once per replay of 16 / 4 steps
     steps, cur, preps = [], [], []
     for r in rows:
         if "k_prep" in r["Kernel_Name"]:
             preps.append(r)
             continue
         cur.append(r)
-        if "k_adam" in r["Kernel_Name"]:
+        n_ = r["Kernel_Name"]
+        if "k_adam" in n_ or "k_small_tn" in n_:      # (k_small_tn: the small nets' weight-gradient launch with the optimiser in its epilogue)
             steps.append(cur)
             cur = []
     steps = [s for s in steps if len(s) == len(names)]

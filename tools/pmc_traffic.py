@@ -51,8 +51,12 @@ names = (["fwd_enc%d" % (k + 1) for k in range(L)] + (["fwd_head+fwd_dec1"] if t
          + ["fwd_dec%d" % (k + 1) for k in range(1 if tail else 0, L)] + ["fwd_out_loss", "bwd_out"]
          + ["bwd_dec%d" % (k + 1) for k in range(L - 1, 0, -1)] + (["bwd_dec1_latent+bwd_head"] if tail else ["bwd_dec1_latent", "bwd_head"])
          + ["bwd_enc%d" % (k + 1) for k in range(L - 1, 0, -1)])
-n_wg = len([k for k in fetch if k != "prep"]) - len(names) - 1            # the step ends with k_adam
-names += (["wgrad"] if n_wg == 1 else ["wgrad%d" % (i + 1) for i in range(n_wg)]) + ["adam"]
+fused_adam = tail and not os.environ.get("AVAE_NO_ADAM_FUSE") and not os.environ.get("AVAE_NO_LEAN")      # small nets: "wgrad+adam" is ONE launch
+if fused_adam:
+    names += ["wgrad+adam"]
+else:
+    n_wg = len([k for k in fetch if k != "prep"]) - len(names) - 1            # the step ends with k_adam
+    names += (["wgrad"] if n_wg == 1 else ["wgrad%d" % (i + 1) for i in range(n_wg)]) + ["adam"]
 res = {"config": label, "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, mean over steps; rocprofv3 --pmc, separate passes",
        "launches": {}}
 for key in ["prep"] + list(range(1, len(names) + 1)):

@@ -126,13 +126,24 @@ struct TnItem {
     int bias_row;            // see WorkItem::bias_row
     int tile_off, tile_cnt;  // this entry covers tiles [tile_off, tile_off + tile_cnt) of the item's tile list: the host cuts
     int pad;                 // items with many tiles into several entries so that the grid (x = longest entry) is not mostly padding
+    // k_small_tn with the optimiser in its epilogue (TnLaunchArgs::adam): the layer's two compute-dtype shadows
+    void* W; void* Wt;       // [M][ldw] (dgrad operand), [N][ldt] (forward operand)
+    int ldw, ldt;
 };
 constexpr int kMaxTnItems = 32;
+struct DevState;
 struct TnLaunchArgs {
     int n_items;
     int grid_x;
     int xcd_group;           // G = 1, 2, 4 or 8 items share the 8 XCDs: each item's tiles run on 8/G of them (see k_grouped)
     int sched;               // as LaunchArgs::sched
+    // Small nets, one replica: the Adam step rides in this launch (k_small_tn<CT, true>) -- a tile's gradient block is applied to the
+    // parameters as it leaves the accumulators, and k_adam's launch disappears.  theta / m / v of an element sit at its gradient's
+    // address + a constant number of floats (the four fp32 arrays share the master layout).
+    int adam;
+    long long d_theta, d_m, d_v;
+    float beta1, beta2, eps;
+    const DevState* st;      // lr_t of this step (published by the K_COST item earlier in the step)
     TnItem items[kMaxTnItems];
 };
 
@@ -343,6 +354,7 @@ void launch_small_latb(int compute_dtype, int act, const LaunchArgs& args, int g
                        unsigned long long* stamps, int launch_id);
 void launch_small_head(int compute_dtype, int act, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s,
                        unsigned long long* stamps, int launch_id);
+void launch_small_tn(int compute_dtype, const TnLaunchArgs& args, int grid_x, int grid_y, hipStream_t s, unsigned long long* stamps, int launch_id);
 void launch_small_loss(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id);
 void launch_small(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id);
 void launch_reduce(const ReduceArgs& a, int n_blocks, hipStream_t s);

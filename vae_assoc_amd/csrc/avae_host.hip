@@ -175,6 +175,7 @@ struct avae_handle {
     std::vector<WorkItem> items;            // training + eval tables (host mirror)
     std::vector<Launch> fwd, bwd;           // training launches: forward, dgrad chain
     std::vector<Launch> wgrad;              // all weight gradients (-> [all-reduce ->] k_adam)
+    std::vector<Launch> wgrad_adam;         // small nets, one replica: the same launch with the Adam step in its epilogue (k_small_tn): no k_adam launch
     // Data-parallel buckets: bucket 0 = the decoder side of every modality (output layer, decoder layers: their weight gradients
     // can be taken as soon as bwd_dec1_latent has run), bucket 1 = the encoder side (heads, encoder layers: after the last dgrad).
     // The all-reduce of bucket 0 runs beside the encoder's dgrad chain and bucket 1's weight gradients; Adam is applied per bucket.
@@ -1465,6 +1466,38 @@ void build_training_plan(avae_handle* h) {
             if (base > 0) h->wgrad.push_back(L);
         }
     }
+    // ---- small nets: the optimiser in the epilogue of the (single) weight-gradient launch.  Only for the plain single-replica step
+    // (under data parallelism the all-reduce sits between the two; avae_step_backward / avae_step_apply keep them apart as well).
+    h->wgrad_adam.clear();
+    if (!any_conv && h->wgrad.size() == 1 && h->wgrad[0].tn && h->wgrad[0].cfg == 0 && h->wgrad[0].targs.xcd_group == 1
+        && !std::getenv("AVAE_NO_LEAN") && !std::getenv("AVAE_NO_ADAM_FUSE")) {
+        Launch L = h->wgrad[0];
+        bool ok = true;
+        for (int i = 0; i < L.targs.n_items && ok; ++i) {
+            TnItem& t = L.targs.items[i];
+            ok = t.ksplit <= 1 && t.bias_row == 0 && t.K > 0;
+            const Dense* dm = nullptr;
+            for (const Mod& md : h->mods) {
+                auto look = [&](const Dense& d) { if (h->grad() + d.master == t.out) dm = &d; };
+                for (const Dense& d : md.enc) look(d);
+                look(md.head);
+                for (const Dense& d : md.dec) look(d);
+                look(md.outl);
+            }
+            ok = ok && dm && t.M == dm->in + 1 && t.N == dm->out && t.ld0 == dm->ld;
+            if (ok) { t.W = h->at<void>(dm->W); t.Wt = h->at<void>(dm->Wt); t.ldw = dm->ldw; t.ldt = dm->ldt; }
+        }
+        if (ok) {
+            L.cfg = 12; L.name = "wgrad+adam";
+            L.targs.adam = 1;
+            L.targs.d_theta = h->at<float>(h->off_theta) - h->grad();
+            L.targs.d_m = h->at<float>(h->off_m) - h->grad();
+            L.targs.d_v = h->at<float>(h->off_v) - h->grad();
+            L.targs.beta1 = h->cfg.beta1; L.targs.beta2 = h->cfg.beta2; L.targs.eps = h->cfg.adam_eps;
+            L.targs.st = h->state();
+            h->wgrad_adam.push_back(L);
+        }
+    }
     // ---- weight warm-up: a launch on the 8-wave NT tiles pulls the weight panels of the next grouped NT launch into the Infinity
     // Cache (see k_grouped); forward and backward form one sequence (the step graph runs them back to back)
     if (!std::getenv("AVAE_NO_WARM")) {
@@ -1648,6 +1681,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         else if (L.cfg == 10) launch_small_latb(h->cfg.compute_dtype, L.lean_act, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else if (L.cfg == 9) launch_small_loss(h->cfg.compute_dtype, L.args, L.grid_x, L.grid_y, L.lds, s, stamps, stamp_base + k);
         else if (L.cfg == 7) launch_small(h->cfg.compute_dtype, L.args, L.grid_x, L.grid_y, L.lds, s, stamps, stamp_base + k);
+        else if (L.tn && L.cfg == 12) launch_small_tn(h->cfg.compute_dtype, L.targs, L.grid_x, L.grid_y, s, stamps, stamp_base + k);
         else if (L.tn) launch_grouped_tn(h->cfg.compute_dtype, L.cfg, L.targs, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else launch_grouped(h->cfg.compute_dtype, L.cfg, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         LAUNCH_OK(L.name);
@@ -1870,6 +1904,10 @@ void init_device(avae_handle* h) {
             };
             if (!h->overlap) {
                 run(h->fwd, 0, h->fwd.size(), cs, stamp_base); run(h->bwd, 0, h->bwd.size(), cs, stamp_base < 0 ? -1 : stamp_base + (int)h->fwd.size());
+                if (!h->wgrad_adam.empty()) {       // the optimiser rides in the weight-gradient launch
+                    run(h->wgrad_adam, 0, 1, cs, stamp_base < 0 ? -1 : stamp_base + (int)(h->fwd.size() + h->bwd.size()));
+                    return;
+                }
                 run(h->wgrad, 0, h->wgrad.size(), cs, stamp_base < 0 ? -1 : stamp_base + (int)(h->fwd.size() + h->bwd.size()));
                 run_adam(h, 0, cs);
                 return;
@@ -2370,8 +2408,8 @@ void train_one(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, c
     }
     run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, s);
     run_launches(h, h->fwd, s); run_launches(h, h->bwd, s);
-    run_launches(h, h->wgrad, s);
-    run_adam(h, 0, s);
+    if (!h->wgrad_adam.empty()) run_launches(h, h->wgrad_adam, s);
+    else { run_launches(h, h->wgrad, s); run_adam(h, 0, s); }
     if (h->timing) {      // floor of the measurement: a one-store kernel (partial slot 0 is rewritten every step anyway)
         Timed t(h, s, "_null_kernel");
         launch_fill(h->at<void>(h->off_partial), 4, 0u, 0, 1, 1, s);

@@ -237,6 +237,15 @@ template <int NW = 4> __device__ __forceinline__ float block_sum(float v, float*
     return t;
 }
 
+// One parameter's TF-1 Adam step -- ONE definition (explicit fused multiply-adds, nothing left to context-dependent contraction) for
+// k_adam and for the weight-gradient launch that carries the optimiser in its epilogue, so that both round alike.
+__device__ __forceinline__ void adam_update(float g, float& m, float& v, float& th, float omb1, float omb2, float lr_t, float eps) {
+#pragma clang fp contract(off)
+    m = __builtin_fmaf(g - m, omb1, m);
+    v = __builtin_fmaf(__builtin_fmaf(g, g, -v), omb2, v);
+    th -= (m * lr_t) / (sqrtf(v) + eps);
+}
+
 // Reconstruction loss of one element and its gradient w.r.t. the logit -- ONE definition for the three kernels that carry the loss
 // epilogue, with floating-point contraction off inside it, so that every route rounds alike (the routes are checked against each other
 // bitwise).  sl = scale * loss, da = scale * dloss/da.
@@ -1840,6 +1849,135 @@ void launch_small_latb(int compute_dtype, int act, const LaunchArgs& args, int g
 #undef K_LATB_F
 }
 
+// ---- the small nets' weight-gradient launch on the lean frame, with the optimiser in its epilogue (tile configuration 12):
+// dW[m][n] = sum_k X[k][m] * dA[k][n], 64x64 tiles, K-major operand images and fragment reads exactly as k_grouped's TN instance
+// (tn_frag_off / tn_frag), MFMA operands swapped so that a lane holds one gradient row's four consecutive columns.  ADAM: the block
+// is applied to theta / m / v as it leaves the accumulators (adam_update, the arithmetic of k_adam), the gradient itself is still
+// stored (avae_get_grads, the cost slot's neighbours), and both compute-dtype shadows of the layer are refreshed -- k_adam's launch,
+// its boundary and the gradient's read-back disappear.  Launches with split-K or all-ones bias rows stay on the general kernel.
+template <typename CT, bool ADAM>
+__global__ void __launch_bounds__(kThreads) k_small_tn(const TnLaunchArgs args, unsigned long long* stamps, int launch_id) {
+    constexpr int BM = 64, RING = 4, ES = (int)sizeof(CT), EPR = kTileBytesK / ES, NCH = 4;
+    constexpr int kStage = 2 * BM * kTileBytesK;               // A part (BM columns) then B part: 16 KiB, EPR k-rows
+    unsigned char* smem = avae_dyn_smem;
+#ifdef AVAE_STAMPS
+    unsigned long long sv[kStampWords] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    AVAE_STAMP(0)
+    const int part = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const TnItem w = args.items[blockIdx.y];
+    asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.tile_off));
+    int t;
+    {
+        const int nt = w.tile_cnt;
+        const int q = nt >> 3, r = nt & 7;
+        if (idx >= q + (part < r ? 1 : 0)) return;
+        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx + w.tile_off;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tm = t / w.tiles_n, tn = t - tm * w.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BM;
+    const int nk = (w.K * ES) / kTileBytesK;
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    const unsigned char* src[NCH];
+    size_t kadv[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int r = (c * 4 + wave) * 8 + (lane >> 3);
+        const bool is_a = c < 2;
+        const int rr = is_a ? r : r - BM, sub = rr / EPR, k = rr - sub * EPR;
+        const int lc = (lane & 7) ^ tn_swz<CT>(k);
+        const size_t ld_b = (size_t)(is_a ? w.lda : w.ldb) * ES;
+        kadv[c] = (size_t)EPR * ld_b;
+        src[c] = reinterpret_cast<const unsigned char*>(is_a ? w.A : w.B) + (size_t)(is_a ? m0 : n0) * ES + (size_t)k * ld_b + (size_t)sub * kTileBytesK + lc * 16;
+    }
+#define AVAE_T_DMA(kt, buf)                                                                                             \
+    { _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                                                   \
+        __builtin_amdgcn_global_load_lds((gp_t)(src[c] + (size_t)(kt) * kadv[c]), (lp_t)(smem + (buf) * kStage + (c * 4 + wave) * 1024), 16, 0, 0); }
+    int offA[2], offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { offA[i] = tn_frag_off<CT>(wr * 32 + i * 16, lane); offB[i] = BM * kTileBytesK + tn_frag_off<CT>(wc * 32 + i * 16, lane); }
+    AVAE_STAMP(1)
+    const int npro = nk < RING - 1 ? nk : RING - 1;
+    for (int p = 0; p < npro; ++p) AVAE_T_DMA(p, p)
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (kt == 0) { AVAE_STAMP(2) }
+        const unsigned char* Sb = smem + buf * kStage;
+        u32x4 a0[2], b0[2], a1[2], b1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { a0[i] = tn_frag<CT>(Sb, offA[i], 0); b0[i] = tn_frag<CT>(Sb, offB[i], 0); }
+        const int fill = buf == 0 ? RING - 1 : buf - 1;
+        if (kt + RING - 1 < nk) AVAE_T_DMA(kt + RING - 1, fill)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { a1[i] = tn_frag<CT>(Sb, offA[i], 1); b1[i] = tn_frag<CT>(Sb, offB[i], 1); }
+        if constexpr (sizeof(CT) == 2) { tn_wait_lds(); tn_frags_ready(a0); tn_frags_ready(b0); tn_frags_ready(a1); tn_frags_ready(b1); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma<CT>(b0[j], a0[i], acc[i][j]);       // swapped: acc[i][j][e] = dW[row fr of block i][col 4 fq + e of block j]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma<CT>(b1[j], a1[i], acc[i][j]);
+        buf = buf + 1 == RING ? 0 : buf + 1;
+    }
+#undef AVAE_T_DMA
+    AVAE_STAMP(3)
+    float lr_t = 0.0f, omb1 = 0.0f, omb2 = 0.0f;
+    if constexpr (ADAM) { lr_t = args.st->lr_t; omb1 = 1.0f - args.beta1; omb2 = 1.0f - args.beta2; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + wr * 32 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 32 + j * 16 + 4 * fq;
+            if (row < w.M && col < w.N) {
+                const int nv = w.N - col;
+                float* gp = w.out + (size_t)row * w.ld0 + col;
+                const float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                store_row<float>(gp, g, nv);
+                if constexpr (ADAM) {
+                    float th[4], m[4], v[4];         // (fetched here: ahead of the K loop they cost more than they hide, 18.1 vs 15.3 us)
+                    load4<float>(gp + args.d_theta, th); load4<float>(gp + args.d_m, m); load4<float>(gp + args.d_v, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) adam_update(g[e], m[e], v[e], th[e], omb1, omb2, lr_t, args.eps);
+                    store_row<float>(gp + args.d_theta, th, nv); store_row<float>(gp + args.d_m, m, nv); store_row<float>(gp + args.d_v, v, nv);
+                    store_row<CT>(reinterpret_cast<CT*>(w.W) + (size_t)row * w.ldw + col, th, nv);
+                    CT* wt = reinterpret_cast<CT*>(w.Wt) + row;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nv) wt[(size_t)(col + e) * w.ldt] = to_ct<CT>(th[e]);
+                }
+            }
+        }
+    }
+    AVAE_STAMP(4)
+    AVAE_STAMP_FLUSH()
+}
+void launch_small_tn(int compute_dtype, const TnLaunchArgs& args, int grid_x, int grid_y, hipStream_t s, unsigned long long* stamps, int launch_id) {
+    const dim3 grid(grid_x, grid_y), block(kThreads);
+    const int lds_bytes = 4 * 2 * 64 * kTileBytesK;
+    if (compute_dtype == AVAE_BF16) {
+        if (args.adam) AVAE_LAUNCH((k_small_tn<__bf16, true>), grid, block, lds_bytes, s, args, stamps, launch_id);
+        else AVAE_LAUNCH((k_small_tn<__bf16, false>), grid, block, lds_bytes, s, args, stamps, launch_id);
+    } else {
+        if (args.adam) AVAE_LAUNCH((k_small_tn<float, true>), grid, block, lds_bytes, s, args, stamps, launch_id);
+        else AVAE_LAUNCH((k_small_tn<float, false>), grid, block, lds_bytes, s, args, stamps, launch_id);
+    }
+}
+
 template <typename CT, int KIND>
 static void launch_small_act(int act, const LaunchArgs& args, dim3 grid, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id) {
     const dim3 block(kThreads);
@@ -1968,11 +2106,7 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
                 load4<float>(w.m + off, m);
                 load4<float>(w.v + off, v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    m[e] += (g[e] - m[e]) * omb1;
-                    v[e] += (g[e] * g[e] - v[e]) * omb2;
-                    th[e] -= (m[e] * lr_t) / (sqrtf(v[e]) + a.eps);
-                }
+                for (int e = 0; e < 4; ++e) adam_update(g[e], m[e], v[e], th[e], omb1, omb2, lr_t, a.eps);
                 const int nv = w.cols - gcol;
                 store_row<float>(w.theta + off, th, nv);
                 store_row<float>(w.m + off, m, nv);
