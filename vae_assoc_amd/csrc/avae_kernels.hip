@@ -1936,30 +1936,66 @@ __global__ void __launch_bounds__(kThreads) k_small_tn(const TnLaunchArgs args, 
     }
 #undef AVAE_T_DMA
     AVAE_STAMP(3)
-    float lr_t = 0.0f, omb1 = 0.0f, omb2 = 0.0f;
-    if constexpr (ADAM) { lr_t = args.st->lr_t; omb1 = 1.0f - args.beta1; omb2 = 1.0f - args.beta2; }
+    if constexpr (!ADAM) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = m0 + wr * 32 + i * 16 + fr;
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + wr * 32 + i * 16 + fr;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 32 + j * 16 + 4 * fq;
-            if (row < w.M && col < w.N) {
-                const int nv = w.N - col;
-                float* gp = w.out + (size_t)row * w.ld0 + col;
-                const float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                store_row<float>(gp, g, nv);
-                if constexpr (ADAM) {
-                    float th[4], m[4], v[4];         // (fetched here: ahead of the K loop they cost more than they hide, 18.1 vs 15.3 us)
-                    load4<float>(gp + args.d_theta, th); load4<float>(gp + args.d_m, m); load4<float>(gp + args.d_v, v);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) adam_update(g[e], m[e], v[e], th[e], omb1, omb2, lr_t, args.eps);
-                    store_row<float>(gp + args.d_theta, th, nv); store_row<float>(gp + args.d_m, m, nv); store_row<float>(gp + args.d_v, v, nv);
-                    store_row<CT>(reinterpret_cast<CT*>(w.W) + (size_t)row * w.ldw + col, th, nv);
-                    CT* wt = reinterpret_cast<CT*>(w.Wt) + row;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (e < nv) wt[(size_t)(col + e) * w.ldt] = to_ct<CT>(th[e]);
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wc * 32 + j * 16 + 4 * fq;
+                if (row < w.M && col < w.N) {
+                    const float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    store_row<float>(w.out + (size_t)row * w.ld0 + col, g, w.N - col);
                 }
+            }
+        }
+    } else {
+        // The optimiser wants the block ROW-contiguous (16 lanes x 16 B = a row's 256 bytes per access, as k_adam reads theta / m / v; from
+        // the accumulators a lane owns one row's 16 bytes and a wave touches 16 rows at 64 bytes: 15.3 us for the launch that way):
+        // accumulators -> an fp32 tile in LDS (the ring is free), then k_adam's tile body on it, W^T through the same tile.
+        constexpr int LDT = 65;
+        float* T = reinterpret_cast<float*>(smem);
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[(wr * 32 + i * 16 + fr) * LDT + wc * 32 + j * 16 + 4 * fq + e] = acc[i][j][e];
+        lds_barrier();
+        const float lr_t = args.st->lr_t, omb1 = 1.0f - args.beta1, omb2 = 1.0f - args.beta2;
+        const int c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = (tid >> 4) + 16 * k;
+            const int grow = m0 + r, gcol = n0 + c4;
+            if (grow < w.M && gcol < w.N) {
+                const int nv = w.N - gcol;
+                float* gp = w.out + (size_t)grow * w.ld0 + gcol;
+                float g[4], th[4], m[4], v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = T[r * LDT + c4 + e];
+                load4<float>(gp + args.d_theta, th); load4<float>(gp + args.d_m, m); load4<float>(gp + args.d_v, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) adam_update(g[e], m[e], v[e], th[e], omb1, omb2, lr_t, args.eps);
+                store_row<float>(gp, g, nv);
+                store_row<float>(gp + args.d_theta, th, nv); store_row<float>(gp + args.d_m, m, nv); store_row<float>(gp + args.d_v, v, nv);
+                store_row<CT>(reinterpret_cast<CT*>(w.W) + (size_t)grow * w.ldw + gcol, th, nv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[r * LDT + c4 + e] = th[e];
+            }
+        }
+        lds_barrier();
+        const int r4 = (tid & 15) * 4;                          // W^T: a lane takes four consecutive rows (m) of one column (n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (tid >> 4) + 16 * k;
+            const int gcol = n0 + c, grow = m0 + r4;
+            if (gcol < w.N && grow < w.M) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = T[(r4 + e) * LDT + c];
+                store_row<CT>(reinterpret_cast<CT*>(w.Wt) + (size_t)gcol * w.ldt + grow, v, w.M - grow);
             }
         }
     }
