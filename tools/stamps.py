@@ -48,7 +48,7 @@ def main():
              'bwd_dec1_latent', 'bwd_head', 'bwd_enc2', 'wgrad']
     if cfg != "c4" and not os.environ.get("AVAE_NO_TAIL"):      # tail products: two launches fewer (avae_host.hip::fuse_tail)
         names = ['fwd_enc1', 'fwd_enc2', 'fwd_head+fwd_dec1', 'fwd_dec2', 'fwd_out_loss', 'bwd_out', 'bwd_dec2',
-                 'bwd_dec1_latent+bwd_head', 'bwd_enc2', 'wgrad']
+                 'bwd_dec1_latent+bwd_head', 'bwd_enc2', 'wgrad(+adam)']
     print("%-16s %6s %8s | %7s %7s %7s %7s | %8s %7s  (us; realtime ticks are 10 ns)" % (
         "launch", "blocks", "span", "lookup", "tile0", "kloop", "epilog", "startspr", "clkMHz"))
     prev_end = None
