@@ -694,6 +694,31 @@ def test_generate_serving_odd_batch_sizes(V, B):
                 assert torch.equal(gen[m], o), (dtype, B, rows, m)
 
 
+@pytest.mark.parametrize("nz", [33, 48, 63])
+def test_generate_serving_wide_latents(V, nz):
+    """the lean per-call serving launch (k_serve_in) stages EVERY latent column -- 32 < n_z <= 63 takes two trips
+    of its 8 threads x 4 columns per row.  fp32 against the oracle, bf16 bitwise against the per-modality avae_decode path (whose
+    staging kernel loops over all n_z), rows on both sides of the 64-row bucket."""
+    archs = [make_arch("image", 784, 96, 80, nz), make_arch("joint", 147, 40, 24, nz)]
+    B = 96
+    rng = np.random.default_rng(nz)
+    model, ref = build_pair(V, archs, [True, False], [50.0, 1.0], 8.0, "relu", B, "fp32")
+    for rows in (1, 33, 64, 65, 200):
+        z = rng.standard_normal((rows, nz)).astype(np.float32)
+        z[:, 32:] *= 3.0                    # the columns the round-2 kernel dropped carry weight
+        gen, rgen = model.generate(z), ref.generate(z)
+        for m in range(2):
+            assert np.abs(gen[m] - rgen[m]).max() <= 1e-5 * max(1, np.abs(rgen[m]).max()), (rows, m)
+    mb = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="softplus", batch_size=B, compute_dtype="bf16", seed=4)
+    for rows in (2, 64, 97):
+        z = torch.as_tensor(rng.standard_normal((rows, nz)).astype(np.float32)).cuda()
+        gen = mb.generate(z)
+        for m in range(2):
+            o = torch.empty((rows, archs[m]["n_input"]), dtype=torch.float32, device="cuda")
+            assert mb._L.avae_decode(mb._h, m, z.data_ptr(), rows, o.data_ptr(), mb._stream()) == 0
+            assert torch.equal(gen[m], o), (nz, rows, m)
+
+
 def test_strided_modalities_from_one_matrix(V):
     """train() hands column slices of one [B, 931] matrix (vae_assoc.py:510,543): no copies."""
     archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]

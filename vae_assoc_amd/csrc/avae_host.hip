@@ -162,7 +162,7 @@ struct avae_handle {
     int B = 0, Bp = 0, ldB = 0;   // batch, batch padded to 128 rows, rup(batch, KU)
     int nz = 0, M = 0, ld_eps = 0;
     std::vector<Mod> mods;
-    size_t P_flat = 0, P_int = 0;            // flat API count, internal padded count (floats)
+    size_t P_flat = 0, P_int = 0, P_enc = 0; // flat API count, internal padded count (floats), floats of the encoder sides (they come first)
     size_t off_theta = 0, off_m = 0, off_v = 0, off_g = 0;   // byte offsets; g has P_int + 64 floats
     size_t stage_lo = 0, stage_bytes = 0;   // input-staging set 0 (X0 / X32 of every modality + eps); sets 1..kMultiSteps-1 follow it
     size_t off_eps = 0, off_partial = 0, off_state = 0, off_items = 0, off_adam = 0, off_inf = 0, off_stamps = 0, off_latent = 0;
@@ -445,6 +445,24 @@ void plan_memory(avae_handle* h) {
         md.mulv = b.take((size_t)B * 2 * nz * 4);
         md.g0 = b.take((size_t)B * 3 * h->ld_eps * 4);  // [g0mu | g0lv | dz/dlv factor], each roundup(n_z, 4) wide
         h->mods.push_back(std::move(md));
+    }
+    // Master layout (theta, m, v, g share it): the ENCODER side of every modality first, then every DECODER side, the step's cost in
+    // the float right behind -- so each data-parallel bucket is ONE contiguous float range (bucket 1 = [0, P_enc), bucket 0 =
+    // [P_enc, P_int + 1)) and the whole buffer one range.  The flat API order (reference creation order) is untouched: it is
+    // mapped through Dense::master.
+    {
+        size_t pm = 0;
+        auto place = [&](Dense& d) { d.master = pm; pm += (size_t)(d.in + 1) * d.ld; };
+        for (Mod& md : h->mods) {
+            if (md.conv) { for (ConvStage& st : md.cenc) place(st.d); md.head = md.cenc[3].d; }
+            else { for (Dense& d : md.enc) place(d); place(md.head); }
+        }
+        h->P_enc = pm;
+        for (Mod& md : h->mods) {
+            if (md.conv) { for (ConvStage& st : md.cdec) place(st.d); md.outl = md.cdec[4].d; }
+            else { for (Dense& d : md.dec) place(d); place(md.outl); }
+        }
+        if (pm != pint) throw Err("internal error: master layout size");
     }
     h->P_int = pint;
     h->P_flat = pflat;
@@ -946,6 +964,8 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
     return L;
 }
 
+void dp_ranges(const avae_handle* h, int* n_buckets, std::vector<avae_handle::Range> (&out)[2]);
+
 void build_training_plan(avae_handle* h) {
     h->items.clear(); h->fwd.clear(); h->bwd.clear(); h->wgrad.clear();
     Builder bd(h, h->items, h->B, true);
@@ -1357,9 +1377,8 @@ void build_training_plan(avae_handle* h) {
         };
         wgrad_launches(wg, h->wgrad, "wgrad");
         // the same weight gradients cut into the two data-parallel buckets (MLP-only models)
-        h->n_buckets = any_conv ? 1 : 2;
         h->wgrad_b[0].clear(); h->wgrad_b[1].clear();
-        h->ranges_b[0].clear(); h->ranges_b[1].clear();
+        dp_ranges(h, &h->n_buckets, h->ranges_b);
         if (h->n_buckets == 2) {
             std::vector<WorkItem> set[2];
             for (Mod& md : h->mods) {
@@ -1369,13 +1388,7 @@ void build_training_plan(avae_handle* h) {
                 set[1].push_back(bd.wgrad(md.E.back(), md.head, md.dH));
                 for (int k = md.L - 1; k >= 1; --k) set[1].push_back(bd.wgrad(md.E[k - 1], md.enc[k], md.dE[k]));
                 set[1].push_back(bd.wgrad(md.X0, md.enc[0], md.dE[0]));
-                // the master layout of a modality is [enc..., head | dec..., out]: one contiguous range per bucket and modality
-                const size_t enc_lo = md.enc[0].master, dec_lo = md.dec[0].master, dec_hi = md.outl.master + (size_t)(md.outl.in + 1) * md.outl.ld;
-                h->ranges_b[1].push_back({enc_lo, dec_lo - enc_lo});
-                h->ranges_b[0].push_back({dec_lo, dec_hi - dec_lo});
             }
-            if (h->ranges_b[0].back().off + h->ranges_b[0].back().count != h->P_int) throw Err("internal error: the cost slot does not follow the last decoder range");
-            h->ranges_b[0].back().count += 1;                    // + the step's cost (final since bwd_dec1_latent)
             wgrad_launches(set[0], h->wgrad_b[0], "wgrad_dec");
             wgrad_launches(set[1], h->wgrad_b[1], "wgrad_enc");
             long wide = 0;
@@ -1387,8 +1400,6 @@ void build_training_plan(avae_handle* h) {
             // small nets: the weight-gradient launch is a fraction of a round of the chip and splits for free; big nets keep it whole
             // (C4: 134 us as one launch, 111 + 119 as two) and only Adam is cut
             h->ov_split_wgrad = wide < 192;
-        } else {
-            h->ranges_b[0].push_back({0, h->P_int + 1});
         }
         for (int i = 1; i <= 3; ++i) if (is_thin(i)) thin_launch("conv_dec" + std::to_string(i + 1) + "_wgrad_direct", h->wgrad, 2, i);
         {   // bias gradients of the adjoint-frame stages = column sums of their output gradient, first level
@@ -2066,19 +2077,16 @@ void comm_init(avae_handle* h) {
     }
 }
 
-// ranges of bucket b, from the memory plan alone (so that avae_dp_plan needs no device)
+// ranges of bucket b, from the memory plan alone (so that avae_dp_plan needs no device): ONE contiguous range per bucket
 void dp_ranges(const avae_handle* h, int* n_buckets, std::vector<avae_handle::Range> (&out)[2]) {
     bool any_conv = false;
     for (const Mod& md : h->mods) any_conv = any_conv || md.conv;
     out[0].clear(); out[1].clear();
-    if (any_conv) { *n_buckets = 1; out[0].push_back({0, h->P_int + 1}); return; }
+    // comm_buckets = 1: north_star's literal design, a single all-reduce of the whole buffer (gradient + cost)
+    if (any_conv || h->cfg.comm_buckets == 1) { *n_buckets = 1; out[0].push_back({0, h->P_int + 1}); return; }
     *n_buckets = 2;
-    for (const Mod& md : h->mods) {
-        const size_t enc_lo = md.enc[0].master, dec_lo = md.dec[0].master, dec_hi = md.outl.master + (size_t)(md.outl.in + 1) * md.outl.ld;
-        out[1].push_back({enc_lo, dec_lo - enc_lo});
-        out[0].push_back({dec_lo, dec_hi - dec_lo});
-    }
-    out[0].back().count += 1;      // + the cost slot (element P_int follows the last modality's output layer)
+    out[1].push_back({0, h->P_enc});                               // encoder sides of every modality
+    out[0].push_back({h->P_enc, h->P_int + 1 - h->P_enc});         // decoder sides + the cost slot (element P_int)
 }
 
 // forward + the backward part of bucket b + its weight gradients, on staging set j

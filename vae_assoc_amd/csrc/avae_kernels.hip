@@ -2788,10 +2788,13 @@ __global__ void __launch_bounds__(kThreads) k_serve_in(ServeInArgs a) {
     {
         const int zrow = tid >> 3, zg = tid & 7;
         if (m0 + zrow < a.call.rows) {
+            // every latent column: 8 threads per row take 4 columns each per trip (n_z up to 63 needs two trips)
+            for (int d0 = 4 * zg; d0 < nz; d0 += 32) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int d = 4 * zg + e;
-                if (d < nz) img_put<CT>(img, zrow, d, a.call.z[(size_t)(m0 + zrow) * nz + d]);
+                for (int e = 0; e < 4; ++e) {
+                    const int d = d0 + e;
+                    if (d < nz) img_put<CT>(img, zrow, d, a.call.z[(size_t)(m0 + zrow) * nz + d]);
+                }
             }
         }
         if (tid < 32) img_put<CT>(img, tid, nz, 1.0f);
