@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AVAE_ABI_VERSION 3
+#define AVAE_ABI_VERSION 4
 #define AVAE_MAX_MODALITIES 4
 #define AVAE_MAX_HIDDEN 8
 
@@ -45,6 +45,10 @@ extern "C" {
 enum { AVAE_ACT_IDENTITY = 0, AVAE_ACT_RELU = 1, AVAE_ACT_SOFTPLUS = 2, AVAE_ACT_SIGMOID = 3, AVAE_ACT_TANH = 4 };
 /* arithmetic type of the GEMM operands (accumulation, losses, latent maths and Adam are fp32) */
 enum { AVAE_F32 = 0, AVAE_BF16 = 1 };
+/* who runs the gradient all-reduce (avae_config.use_comm) */
+enum { AVAE_COMM_NONE = 0, AVAE_COMM_RCCL = 1, AVAE_COMM_IPC = 2 };
+#define AVAE_IPC_HANDLE_BYTES 128
+#define AVAE_MAX_WORLD 8
 
 typedef struct avae_modality {
     int32_t n_input;                    /* reference network_architecture["n_input"] */
@@ -77,18 +81,25 @@ typedef struct avae_config {
     uint64_t seed;                      /* Philox key of the internal eps generator */
     void* workspace;                    /* optional caller-owned device memory (>= avae_workspace_bytes); NULL -> hipMalloc */
     size_t workspace_bytes;
-    /* Library-owned gradient collective (the reference is single-process, vae_assoc.py:66).  use_comm = 1:
-     * avae_create builds an RCCL communicator of world_size ranks from nccl_id (the 128 bytes of an ncclUniqueId made by
-     * avae_comm_unique_id on rank 0 and handed to every rank by whatever bootstrap the host has -- torch.distributed here);
-     * avae_train_step(s) then run backward -> ncclAllReduce -> Adam per bucket on the library's own streams, the all-reduce of
-     * the decoder-side bucket overlapping the encoder's backward pass.  use_comm = 0: no communicator; a host that owns the
-     * collective drives the same buckets through avae_dp_backward / avae_dp_apply (or the unbucketed avae_step_backward /
-     * avae_step_apply seam).  batch_global / row_offset above stay the caller's to set (world_size*batch_size, rank*batch_size). */
-    int32_t use_comm;
+    /* Library-owned gradient collective (the reference is single-process, vae_assoc.py:66).
+     * use_comm = AVAE_COMM_RCCL: avae_create builds an RCCL communicator of world_size ranks from nccl_id (the 128 bytes of an
+     *   ncclUniqueId made by avae_comm_unique_id on rank 0 and handed to every rank by whatever bootstrap the host has --
+     *   torch.distributed here); the collective is ncclAllReduce on the library's comm stream.
+     * use_comm = AVAE_COMM_IPC: the library's own one-shot all-reduce over hipIpc peers (push reduce-scatter + push all-gather,
+     *   every xGMI link at once).  avae_create allocates the replica's exchange block; the host hands every
+     *   rank's avae_comm_ipc_handle bytes round and calls avae_comm_ipc_attach before the first step.
+     * Either way avae_train_step(s) run backward -> all-reduce -> Adam per bucket on the library's own streams, the decoder-side
+     * bucket's all-reduce overlapping the encoder's backward pass, sixteen steps per captured hipGraph.
+     * use_comm = AVAE_COMM_NONE: a host that owns the collective drives the same buckets through avae_stage_batches /
+     * avae_dp_backward / avae_dp_apply.  batch_global / row_offset above stay the caller's to set (world_size*batch_size,
+     * rank*batch_size). */
+    int32_t use_comm;                   /* AVAE_COMM_* */
     int32_t world_size;
     int32_t rank;
-    int32_t reserved2;
+    int32_t comm_buckets;               /* 0 or 2: two buckets (decoder side first); 1: ONE all-reduce of the whole gradient buffer */
     uint8_t nccl_id[128];
+    int32_t wire_dtype;                 /* AVAE_F32 (default) | AVAE_BF16: gradient element type on the wire; the cost slot is always fp32 */
+    int32_t reserved2[3];
 } avae_config;
 
 typedef struct avae_handle avae_handle;
@@ -130,29 +141,26 @@ int avae_train_step(avae_handle* h, const float* const* x_dev, const int32_t* x_
  * cost is in avae_cost_history. */
 int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev, const int32_t* x_ld,
                      const float* eps_dev, float* cost_host, void* stream);
-/* The same step cut at the data-parallel seam: backward leaves the local gradient (internal
- * padded layout, pads zero) and, in the last float, the local cost in one contiguous device
- * buffer -- SUM-all-reduce that buffer across replicas, then apply. */
-int avae_step_backward(avae_handle* h, const float* const* x_dev, const int32_t* x_ld,
-                       const float* eps_dev, void* stream);
-int avae_step_apply(avae_handle* h, float* cost_host, void* stream);
-/* The same seam for a run of consecutive batches (layout as in avae_train_steps): ONE staging launch for up to 16
- * batches, then per step j = 0..n-1: avae_step_backward_staged(j) -> all-reduce -> avae_step_apply. */
+/* ---- the data-parallel seam (the reference has none: one tf.InteractiveSession, vae_assoc.py:66).  The gradient buffer is ONE
+ * device array of avae_grad_buffer's n_floats: the local gradient in the master layout (encoder sides of every modality, then
+ * decoder sides, pads zero) with the local cost in its last float.  It is cut into buckets of ONE contiguous range each:
+ * bucket 0 = decoder sides + the cost slot, bucket 1 = encoder sides; comm_buckets = 1 and models with a conv modality have the
+ * single bucket 0 = the whole buffer.  avae_dp_plan is host-only (no GPU needed): offs/counts hold n_buckets entries.
+ * Host-owned collective:  avae_stage_batches(n) ; per step j:  avae_dp_backward(j, 0) -> SUM-all-reduce bucket 0's range ->
+ * avae_dp_backward(j, 1) -> all-reduce bucket 1's range -> avae_dp_apply(0) -> avae_dp_apply(1). */
 int avae_stage_batches(avae_handle* h, int32_t n_steps, const float* const* x_dev, const int32_t* x_ld,
                        const float* eps_dev, void* stream);
-int avae_step_backward_staged(avae_handle* h, int32_t j, void* stream);
 int avae_grad_buffer(avae_handle* h, float** dev_ptr, size_t* n_floats);
-/* ---- bucketed data-parallel step.  Bucket 0 = decoder side of every modality (+ the cost slot), bucket 1 = encoder side; models
- * with a conv modality have the single bucket 0.  Each bucket is a few contiguous float ranges of the gradient buffer.
- * avae_dp_plan is host-only (no GPU needed): ranges of the configuration's buckets, offs/counts hold up to
- * 2*AVAE_MAX_MODALITIES entries, n_ranges[b] of them belong to bucket b (bucket 0 first).
- * Host-owned collective:  avae_stage_batches(n) ; per step j:  avae_dp_backward(j, 0) -> all-reduce bucket 0's ranges ->
- * avae_dp_backward(j, 1) -> all-reduce bucket 1's ranges -> avae_dp_apply(0) -> avae_dp_apply(1). */
 int avae_dp_plan(const avae_config* cfg, int32_t* n_buckets, int32_t* n_ranges, int64_t* offs, int64_t* counts);
 int avae_dp_backward(avae_handle* h, int32_t j, int32_t bucket, void* stream);
 int avae_dp_apply(avae_handle* h, int32_t bucket, float* cost_host, void* stream);
 /* 128 bytes of a fresh ncclUniqueId (rank 0 calls this; every rank passes the same bytes in avae_config.nccl_id). */
 int avae_comm_unique_id(void* id128);
+/* AVAE_COMM_IPC bring-up: AVAE_IPC_HANDLE_BYTES describing this replica's exchange block (a hipIpcMemHandle_t + its size and
+ * rank); the host gathers every rank's bytes IN RANK ORDER and hands all world_size * AVAE_IPC_HANDLE_BYTES to attach, which maps
+ * the peers' blocks.  Both are collective in the sense that every rank must call them before any rank trains. */
+int avae_comm_ipc_handle(avae_handle* h, void* handle_out);
+int avae_comm_ipc_attach(avae_handle* h, const void* handles_by_rank);
 /* Costs of the most recent `n` applied steps (oldest first), without having synchronised per step. */
 int avae_cost_history(avae_handle* h, int32_t n, float* host_dst, int64_t* last_step);
 
@@ -183,7 +191,7 @@ int avae_reconstruct(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld
 int avae_save(avae_handle* h, const char* path);
 int avae_load(avae_handle* h, const char* path);
 
-/* Introspection used by bench.py / tests. */
+/* ---- AVAE_INTROSPECTION: bench.py / tests only; no caller of the reference's surface needs anything below ---- */
 int avae_synchronize(avae_handle* h);
 /* Average device time (ms) of every launch of the step over the calls since the last reset,
  * measured with hipEvents on the stream the kernels were launched on (hipExtLaunchKernel start/stop

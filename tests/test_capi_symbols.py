@@ -114,15 +114,16 @@ def test_bench_accounting_matches_survey_figures():
 
 
 def test_dp_plan_is_host_only_and_tiles_the_gradient_buffer(capi):
-    """avae_dp_plan (no GPU needed): the data-parallel buckets of a configuration.  MLP models: bucket 0 = decoder side of every
-    modality + the cost slot, bucket 1 = encoder side; the ranges are disjoint and tile [0, P_int + 1) exactly, and P_int carries
-    less than one 128-byte line of padding per matrix row over the reference's parameter count (no K padding on the wire).  A
-    conv modality: one bucket."""
+    """avae_dp_plan (no GPU needed): the data-parallel buckets of a configuration.  MLP models: the master layout holds the encoder
+    side of EVERY modality first, then every decoder side, then the cost slot, so that bucket 1 (encoder) and bucket 0 (decoder +
+    cost) are ONE contiguous range each (VERDICT r2 #2a: two collectives per step instead of 2 x modalities) that tile
+    [0, P_int + 1) exactly; comm_buckets = 1 gives the single all-reduce of the whole buffer (north_star's literal design); P_int
+    carries less than one 128-byte line of padding per matrix row over the reference's parameter count.  A conv modality: one bucket."""
     L = capi.lib()
 
     def plan(cfg):
         nb, nr = C.c_int32(0), (C.c_int32 * 2)()
-        offs, cnts = (C.c_int64 * 8)(), (C.c_int64 * 8)()
+        offs, cnts = (C.c_int64 * 2)(), (C.c_int64 * 2)()
         assert L.avae_dp_plan(C.byref(cfg), C.byref(nb), nr, offs, cnts) == 0
         out, k = [], 0
         for b in range(2):
@@ -130,24 +131,44 @@ def test_dp_plan_is_host_only_and_tiles_the_gradient_buffer(capi):
             k += nr[b]
         return nb.value, out
     nb, (b0, b1) = plan(_config(capi, B=256))
-    assert nb == 2 and len(b0) == 2 and len(b1) == 2
-    spans = sorted(b0 + b1)
-    assert spans[0][0] == 0
-    for (o0, c0), (o1, _c1) in zip(spans, spans[1:]):
-        assert o0 + c0 == o1, "ranges must tile the buffer without gaps or overlap"
-    total = spans[-1][0] + spans[-1][1]            # = P_int + 1 (cost slot)
+    assert nb == 2 and len(b0) == 1 and len(b1) == 1
+    (o1, c1), (o0, c0) = b1[0], b0[0]
+    assert o1 == 0 and o0 == c1, "encoder sides first, decoder sides + cost right behind: no gap, no overlap"
+    total = o0 + c0                                 # = P_int + 1 (cost slot)
     P = 1468611
-    rows = 2 * (785 + 501 + 501 + 21 + 501 + 501) + 0  # matrix rows of img; jnt below
     rows = (785 + 501 + 501 + 21 + 501 + 501) + (148 + 201 + 201 + 21 + 201 + 201)
     assert P + 1 <= total <= P + 1 + 31 * rows      # rows are whole 128-byte lines, not padded to the K unit
     assert (total - 1) * 4 < 1.05 * P * 4           # C2: 6.13 MB on the wire for 5.87 MB of parameters (6.6 MB with K padding)
-    # encoder side of modality 0 starts the buffer; the decoder side of the LAST modality ends it and carries the cost
-    assert b1[0][0] == 0 and b0[-1][0] + b0[-1][1] == total
-    enc0 = 785 * 500 + 501 * 500 + 501 * 40
-    assert b1[0][1] == 785 * 512 + 501 * 512 + 501 * 64    # 500 -> 512, 40 -> 64 floats per row
+    # encoder sides of both modalities: 500 -> 512, 200 -> 224, 40 -> 64 floats per row
+    assert c1 == (785 * 512 + 501 * 512 + 501 * 64) + (148 * 224 + 201 * 224 + 201 * 64)
+    assert c1 % 32 == 0 and (c0 - 1) % 32 == 0      # whole 128-byte lines: the exchange kernels move 8-float granules
+    for world in range(1, 9):
+        cfg = _config(capi, B=256)
+        cfg.use_comm, cfg.world_size, cfg.rank = capi.COMM_IPC, world, world - 1
+        assert plan(cfg) == (2, [b0, b1])           # the plan does not depend on the collective's backend or the rank
+    cfg = _config(capi, B=256)
+    cfg.comm_buckets = 1
+    nb, (s0, s1) = plan(cfg)
+    assert nb == 1 and s0 == [(0, total)] and s1 == []
     cfg = _config(capi, B=64)
     cfg.mod[0].hidden_conv = 1
     cfg.mod[0].n_hidden[0], cfg.mod[0].n_hidden[1] = 8, 16
     cfg.mod[0].conv_gener[0], cfg.mod[0].conv_gener[1] = 16, 8
     nb, (b0, b1) = plan(cfg)
     assert nb == 1 and len(b0) == 1 and b1 == [] and b0[0][0] == 0
+
+
+def test_config_struct_matches_the_header(capi):
+    """The ctypes mirror of avae_config has the size and field offsets the C compiler gives include/avae.h."""
+    import subprocess
+    import tempfile
+    src = """#include <stdio.h>\n#include <stddef.h>\n#include "avae.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %d\\n",sizeof(avae_config),sizeof(avae_modality),
+offsetof(avae_config,seed),offsetof(avae_config,use_comm),offsetof(avae_config,comm_buckets),offsetof(avae_config,nccl_id),offsetof(avae_config,wire_dtype),AVAE_ABI_VERSION);return 0;}"""
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()
+    Cf = capi.Config
+    want = [C.sizeof(Cf), C.sizeof(capi.Modality), Cf.seed.offset, Cf.use_comm.offset, Cf.comm_buckets.offset, Cf.nccl_id.offset,
+            Cf.wire_dtype.offset, capi.AVAE_ABI_VERSION]
+    assert [int(x) for x in out] == want, (out, want)

@@ -1,0 +1,180 @@
+"""The library-owned gradient collectives on the GPU box (the reference has none, vae_assoc.py:66).
+
+AVAE_COMM_IPC -- the hand-written one-shot all-reduce over hipIpc peers (avae_comm.hip) -- is exercised for real with 2 and 4
+processes sharing the one MI355X (hipIpc works between processes on one device; RCCL refuses two ranks on one device): exported
+exchange blocks, flag hand-shake, shard indexing, fp32 and bf16 wire, one and two buckets, single steps and captured runs of 16,
+against (a) the torch.distributed (gloo) collective over the same buckets -- bitwise for two ranks on the fp32 wire -- and (b) the
+single-replica run at the global batch.  What a one-GPU box cannot show is xGMI itself: peers on other devices."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import make_arch, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+ARCHS = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]       # the C2 / C3 nets
+KW = dict(binary=[True, False], transfer_fct="relu", weights=[50.0, 1.0], assoc_lambda=8.0, seed=3)
+B_LOC, STEPS, RUN = 64, 3, 20
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data(world):
+    rng = np.random.default_rng(29)
+    n = B_LOC * world
+    X = synth_batch(rng, n * (STEPS + RUN), [784, 147], [True, False])
+    eps = rng.standard_normal((STEPS + RUN, n, 20)).astype(np.float32)
+    return X, eps
+
+
+def _shard(X, eps, world, rank, s):
+    """rows of `rank` inside global batch s"""
+    n = B_LOC * world
+    lo, hi = s * n + rank * B_LOC, s * n + (rank + 1) * B_LOC
+    return [x[lo:hi] for x in X], eps[s][rank * B_LOC:(rank + 1) * B_LOC]
+
+
+def _worker(rank, world, port, out_dir, variants):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AVAE_IPC_TIMEOUT_MS="8000")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as g
+        g.build()
+        from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+        X, eps = _data(world)
+        for name, kw in variants:
+            m = AssocVariationalAutoEncoder(ARCHS, batch_size=B_LOC, device=0, data_parallel=True, **dict(KW, **kw))
+            assert m._comm == kw.get("comm", "torch"), (name, m._comm)          # no silent fallback to torch.distributed
+            assert m._cfg.batch_global == B_LOC * world and m._cfg.row_offset == rank * B_LOC
+            costs = []
+            for s in range(STEPS):
+                xs, es = _shard(X, eps, world, rank, s)
+                costs.append(m.partial_fit(xs, es))
+            run_x = [np.concatenate([_shard(X, eps, world, rank, STEPS + i)[0][k] for i in range(RUN)]) for k in range(2)]
+            run_e = np.concatenate([_shard(X, eps, world, rank, STEPS + i)[1] for i in range(RUN)])
+            m.partial_fit_steps(run_x, RUN, run_e, return_cost=False)            # 16 in one captured graph + 4
+            hist = m.cost_history(STEPS + RUN)
+            assert np.array_equal(hist[:STEPS], np.array(costs, dtype=np.float32))
+            np.savez(os.path.join(out_dir, "%s_r%d.npz" % (name, rank)), hist=hist, params=m.get_params())
+            del m
+            dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _single(world, dtype):
+    import __graft_entry__ as g
+    g.build()
+    from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+    X, eps = _data(world)
+    n = B_LOC * world
+    full = AssocVariationalAutoEncoder(ARCHS, batch_size=n, compute_dtype=dtype, device=0, **KW)
+    full.partial_fit_steps(X, STEPS + RUN, eps.reshape(-1, 20), return_cost=False)
+    return full.cost_history(STEPS + RUN), full.get_params()
+
+
+def _load(out_dir, name, world):
+    return [np.load(os.path.join(out_dir, "%s_r%d.npz" % (name, k))) for k in range(world)]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_ipc_allreduce_two_processes(tmp_path, dtype):
+    """N = 2 on one MI355X: the IPC all-reduce (two buckets, and as ONE all-reduce of the whole buffer) is bitwise the gloo
+    collective on the fp32 wire (a two-term sum has one order); on the bf16 wire the replicas stay bit-identical and the costs stay
+    within north_star's 1e-3 of the fp32-wire run."""
+    variants = [("torch", dict(comm="torch", compute_dtype=dtype)),
+                ("ipc2", dict(comm="ipc", compute_dtype=dtype)),
+                ("ipc1", dict(comm="ipc", comm_buckets=1, compute_dtype=dtype)),
+                ("ipc2_bf16", dict(comm="ipc", wire_dtype="bf16", compute_dtype=dtype))]
+    mp.spawn(_worker, args=(2, _port(), str(tmp_path), variants), nprocs=2, join=True)
+    ref_hist, ref_params = _single(2, dtype)
+    t = _load(str(tmp_path), "torch", 2)
+    for name in ("ipc2", "ipc1"):
+        r = _load(str(tmp_path), name, 2)
+        assert np.array_equal(r[0]["params"], r[1]["params"]) and np.array_equal(r[0]["hist"], r[1]["hist"]), name
+        assert np.array_equal(r[0]["params"], t[0]["params"]) and np.array_equal(r[0]["hist"], t[0]["hist"]), name
+    tol = 1e-5 if dtype == "fp32" else 3e-4
+    assert np.allclose(t[0]["hist"], ref_hist, rtol=tol)
+    assert np.abs(t[0]["params"] - ref_params).max() <= (5e-4 if dtype == "fp32" else 2.5e-2)
+    w = _load(str(tmp_path), "ipc2_bf16", 2)
+    assert np.array_equal(w[0]["params"], w[1]["params"]) and np.array_equal(w[0]["hist"], w[1]["hist"])
+    rel = np.abs(w[0]["hist"] - t[0]["hist"]) / np.abs(t[0]["hist"])
+    assert rel.max() <= 1e-3, "bf16 wire: cost drift %.2e over %d steps" % (rel.max(), STEPS + RUN)
+    assert rel[0] == 0.0                                  # the first step's cost is the pre-update forward pass: untouched by the wire
+
+
+def test_ipc_allreduce_four_processes(tmp_path):
+    """N = 4 (shards, chunk indexing and flags for more than one peer), fp32 and bf16 wire, against gloo over the same buckets:
+    a 4-term sum is added in rank order by the shard's owner (gloo's order is its own): equal to accumulation-order rounding."""
+    variants = [("torch", dict(comm="torch", compute_dtype="fp32")), ("ipc2", dict(comm="ipc", compute_dtype="fp32")),
+                ("ipc1_bf16", dict(comm="ipc", comm_buckets=1, wire_dtype="bf16", compute_dtype="fp32"))]
+    mp.spawn(_worker, args=(4, _port(), str(tmp_path), variants), nprocs=4, join=True)
+    ref_hist, ref_params = _single(4, "fp32")
+    t = _load(str(tmp_path), "torch", 4)
+    r = _load(str(tmp_path), "ipc2", 4)
+    for k in range(1, 4):
+        assert np.array_equal(r[0]["params"], r[k]["params"]) and np.array_equal(r[0]["hist"], r[k]["hist"])
+    assert np.allclose(r[0]["hist"], t[0]["hist"], rtol=1e-5) and np.allclose(r[0]["hist"], ref_hist, rtol=1e-5)
+    assert np.abs(r[0]["params"] - ref_params).max() <= 5e-4
+    w = _load(str(tmp_path), "ipc1_bf16", 4)
+    for k in range(1, 4):
+        assert np.array_equal(w[0]["params"], w[k]["params"])
+    assert (np.abs(w[0]["hist"] - ref_hist) / np.abs(ref_hist)).max() <= 1e-3
+
+
+@pytest.mark.parametrize("comm", ["ipc", "library"])
+@pytest.mark.parametrize("kw", [dict(), dict(comm_buckets=1)])
+def test_one_rank_collective_is_the_plain_step(comm, kw):
+    """comm='ipc' / 'library' with no torch.distributed at all: a one-rank exchange (the sum over one rank is the identity) -- the C
+    ABI's collective has no dependency on torch; 3 single steps + a run of 18 are bitwise the plain run's, with two buckets and with
+    the single all-reduce."""
+    import __graft_entry__ as g
+    g.build()
+    from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+    rng = np.random.default_rng(5)
+    archs = [make_arch("image", 784, 64, 48, 20), make_arch("joint", 147, 40, 32, 20)]
+    X = synth_batch(rng, 18 * 32, [784, 147], [True, False])
+    res = []
+    for c in (None, comm):
+        m = AssocVariationalAutoEncoder(archs, batch_size=32, compute_dtype="bf16", device=0, comm=c, **dict(KW, **(kw if c else {})))
+        assert m._comm_lib == (c is not None) and len(m._buckets) == (2 if not (c and kw) else 1)
+        costs = [m.partial_fit([x[i * 32:(i + 1) * 32] for x in X]) for i in range(3)]
+        m.partial_fit_steps(X, 18, return_cost=False)
+        res.append((costs, m.cost_history(21).copy(), m.get_params()))
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_bf16_wire_on_the_rccl_path_one_rank():
+    """wire_dtype='bf16' with the RCCL backend (one rank): pack -> ncclAllReduce(bf16) + the cost in fp32 -> unpack.  The reduced
+    gradient is the local one rounded to bf16: the first cost is exact, the weights move as Adam moves them on a gradient with
+    2^-9 relative noise."""
+    import __graft_entry__ as g
+    g.build()
+    from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+    rng = np.random.default_rng(6)
+    X = synth_batch(rng, 4 * 64, [784, 147], [True, False])
+    ms = [AssocVariationalAutoEncoder(ARCHS, batch_size=64, compute_dtype="fp32", device=0, comm=c, wire_dtype=w, **KW)
+          for c, w in ((None, "fp32"), ("library", "bf16"))]
+    hist = []
+    for m in ms:
+        m.partial_fit_steps(X, 4, return_cost=False)
+        hist.append(m.cost_history(4).copy())
+    g0, g1 = ms[0].get_grads().astype(np.float64), ms[1].get_grads().astype(np.float64)
+    assert hist[0][0] == hist[1][0]
+    assert np.abs(hist[0] - hist[1]).max() <= 1e-3 * np.abs(hist[0]).max()
+    # the last step's gradients: bf16-rounded on the wire (and computed from slightly different weights)
+    assert np.abs(g1 - g0).max() <= 2e-2 * np.abs(g0).max()
+    as_bf16 = torch.as_tensor(g1.astype(np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+    assert np.array_equal(as_bf16, g1.astype(np.float32)), "what Adam consumed is exactly representable in bf16"

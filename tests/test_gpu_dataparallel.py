@@ -1,6 +1,6 @@
 """Data-parallel path of the HIP replicas on the GPU box: two ranks (both on cuda:0, gloo backend -- RCCL
 refuses two ranks on one device) run vae_assoc_amd's own partial_fit with data_parallel=True, i.e.
-avae_step_backward -> SUM all-reduce of the flat gradient(+cost) view -> avae_step_apply, and must
+avae_stage_batches / avae_dp_backward -> SUM all-reduce of the bucket's range of the gradient(+cost) view -> avae_dp_apply, and must
 reproduce the single-replica global-batch run: same costs, same parameters."""
 import os
 import socket
@@ -44,7 +44,7 @@ def _worker(rank, port, out_dir, dtype, conv=False):
         lo, hi = rank * B_LOC, (rank + 1) * B_LOC
         costs = [m.partial_fit([x[lo:hi] for x in X], eps[s][lo:hi]) for s in range(STEPS)]
         ev = m.evaluate_cost([x[lo:hi] for x in X], eps[0][lo:hi])          # summed over ranks inside
-        # the same steps as one run (avae_stage_batches + avae_step_backward_staged): must be bitwise the same
+        # the same steps as one run (avae_stage_batches(n) + avae_dp_backward(j, b)): must be bitwise the same
         m2 = AssocVariationalAutoEncoder(ARCHS, batch_size=B_LOC, compute_dtype=dtype, device=0, data_parallel=True, **KW)
         run_x = [np.concatenate([x[lo:hi]] * STEPS) for x in X]
         run_eps = np.concatenate([eps[s][lo:hi] for s in range(STEPS)])
@@ -162,21 +162,3 @@ def test_rccl_backend_collective_on_the_gradient_view():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "library-owned RCCL communicator: weights and costs equal to the single-replica run: True" in r.stdout
     assert "torch-owned collective over the same buckets: weights and costs equal to the single-replica run: True" in r.stdout
-
-
-def test_library_comm_without_process_group():
-    """comm='library' with no torch.distributed at all: a one-rank communicator (ncclUniqueId drawn and consumed locally) -- the
-    C ABI's collective has no dependency on torch; 3 single steps + a run of 18 are bitwise the plain run's."""
-    import __graft_entry__ as g
-    g.build()
-    from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
-    rng = np.random.default_rng(5)
-    X = synth_batch(rng, 18 * B_LOC, [784, 147], [True, False])
-    res = []
-    for comm in (None, "library"):
-        m = AssocVariationalAutoEncoder(ARCHS, batch_size=B_LOC, compute_dtype="bf16", device=0, comm=comm, **KW)
-        assert m._comm_lib == (comm == "library")
-        costs = [m.partial_fit([x[i * B_LOC:(i + 1) * B_LOC] for x in X]) for i in range(3)]
-        m.partial_fit_steps(X, 18, return_cost=False)
-        res.append((costs, m.cost_history(21).copy(), m.get_params()))
-    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])

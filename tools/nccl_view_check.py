@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sanity check of the gradient collective with the RCCL backend and ONE rank (all a one-GPU box offers), in a process of its own:
-  a) comm='library' (the default under an nccl process group): libavae's own communicator -- ncclUniqueId from rank 0 handed round
+  a) comm='library': libavae's own communicator -- ncclUniqueId from rank 0 handed round
      by torch.distributed, ncclCommInitRank inside avae_create, per step: backward part -> ncclAllReduce of the bucket's ranges on
      the library's comm stream -> Adam per bucket (avae_host.hip::dp_step), driven by avae_train_step / avae_train_steps;
   b) comm='torch': the same buckets through torch.distributed.all_reduce on views of the library's workspace
@@ -33,7 +33,7 @@ ref.partial_fit_steps(X, 21, return_cost=False)
 ref.partial_fit([x[:B] for x in X], return_cost=False)
 ok = True
 
-a = AssocVariationalAutoEncoder(archs, data_parallel=True, **kw)            # nccl backend -> comm='library'
+a = AssocVariationalAutoEncoder(archs, data_parallel=True, comm="library", **kw)
 assert a._comm_lib and a._cfg.use_comm == 1 and len(a._buckets) == 2
 print("buckets (float ranges of the gradient buffer):", a._buckets)
 a.partial_fit_steps(X, 21, return_cost=False)                                # 16 + 5 staged batches, bucketed pipeline per step

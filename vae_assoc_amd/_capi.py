@@ -12,9 +12,12 @@ import threading
 
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
-AVAE_ABI_VERSION = 3
+AVAE_ABI_VERSION = 4
 AVAE_MAX_MODALITIES = 4
 AVAE_MAX_HIDDEN = 8
+AVAE_MAX_WORLD = 8
+AVAE_IPC_HANDLE_BYTES = 128
+COMM_NONE, COMM_RCCL, COMM_IPC = 0, 1, 2
 
 ACT_IDS = {"identity": 0, "relu": 1, "softplus": 2, "sigmoid": 3, "tanh": 4}
 DTYPE_IDS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
@@ -26,8 +29,8 @@ LIB_PATH = os.path.join(_HERE, "libavae.so")
 SYMBOLS = [
     "avae_workspace_bytes", "avae_create", "avae_destroy", "avae_last_error", "avae_param_count",
     "avae_get_params", "avae_set_params", "avae_get_grads", "avae_get_opt_state", "avae_set_opt_state",
-    "avae_train_step", "avae_train_steps", "avae_step_backward", "avae_step_apply", "avae_stage_batches", "avae_step_backward_staged", "avae_grad_buffer", "avae_cost_history",
-    "avae_dp_plan", "avae_dp_backward", "avae_dp_apply", "avae_comm_unique_id",
+    "avae_train_step", "avae_train_steps", "avae_stage_batches", "avae_grad_buffer", "avae_cost_history",
+    "avae_dp_plan", "avae_dp_backward", "avae_dp_apply", "avae_comm_unique_id", "avae_comm_ipc_handle", "avae_comm_ipc_attach",
     "avae_eval_cost", "avae_encode", "avae_decode", "avae_generate", "avae_reconstruct", "avae_save", "avae_load",
     "avae_synchronize", "avae_timing_enable", "avae_timing_report", "avae_debug_fetch",
 ]
@@ -49,8 +52,8 @@ class Config(C.Structure):
                 ("assoc_lambda", C.c_float), ("learning_rate", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
                 ("seed", C.c_uint64), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("use_comm", C.c_int32), ("world_size", C.c_int32), ("rank", C.c_int32), ("reserved2", C.c_int32),
-                ("nccl_id", C.c_uint8 * 128)]
+                ("use_comm", C.c_int32), ("world_size", C.c_int32), ("rank", C.c_int32), ("comm_buckets", C.c_int32),
+                ("nccl_id", C.c_uint8 * 128), ("wire_dtype", C.c_int32), ("reserved2", C.c_int32 * 3)]
 
 
 _lib = None
@@ -82,16 +85,15 @@ def lib():
             L.avae_set_opt_state.argtypes = [vp, vp, vp, C.c_int64]
             L.avae_train_step.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), vp, fp, vp]
             L.avae_train_steps.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), vp, fp, vp]
-            L.avae_step_backward.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), vp, vp]
-            L.avae_step_apply.argtypes = [vp, fp, vp]
             L.avae_stage_batches.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), vp, vp]
-            L.avae_step_backward_staged.argtypes = [vp, i32, vp]
             L.avae_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
             L.avae_cost_history.argtypes = [vp, i32, vp, C.POINTER(C.c_int64)]
             L.avae_dp_plan.argtypes = [C.POINTER(Config), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
             L.avae_dp_backward.argtypes = [vp, i32, i32, vp]
             L.avae_dp_apply.argtypes = [vp, i32, fp, vp]
             L.avae_comm_unique_id.argtypes = [vp]
+            L.avae_comm_ipc_handle.argtypes = [vp, vp]
+            L.avae_comm_ipc_attach.argtypes = [vp, vp]
             L.avae_eval_cost.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), vp, fp, vp]
             L.avae_encode.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp]
             L.avae_decode.argtypes = [vp, i32, vp, i32, vp, vp]

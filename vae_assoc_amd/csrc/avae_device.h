@@ -330,6 +330,36 @@ void launch_serve_in(int compute_dtype, const ServeInArgs& a, int grid_x, hipStr
 void launch_gather(int compute_dtype, const GatherArgs& a, int n_blocks, hipStream_t s);
 void launch_col2im(int compute_dtype, const Col2imArgs& a, int n_blocks, hipStream_t s);
 
+// ---- gradient exchange (avae_comm.hip)
+// One-shot all-reduce over hipIpc peers ("a hand-rolled P2P reduce-scatter/all-gather over hipIpc peers"):
+// every rank owns an exchange block (uncached device memory, mapped by every peer); a range of the gradient buffer is cut into
+// `world` shards of 8-float granules, shard j is reduced by rank j:
+//   phase 1  push     rank r stores its values of shard j into slot r of rank j's block           (all 7 links at once)
+//   phase 2  reduce   rank j adds slots 0..world-1 in RANK ORDER (its own from g), stores the sum into every rank's result area
+//   phase 3  collect  every rank copies the other shards' sums from its result area into g
+// Workgroup w of every rank works on chunk w of every shard and signals / waits on workgroup w of its peers only (a flag word per
+// (workgroup, source rank), value = the call's sequence number), so there is no grid barrier and no reset; every wait is bounded by
+// a wall-clock timeout that raises the block's error word instead of hanging.  Cross-GPU traffic is stores only (posted writes).
+constexpr int kMaxWorld = 8;
+constexpr int kIpcThreads = 256;
+struct IpcArgs {
+    float* g;                       // local gradient buffer (master layout + cost slot)
+    long long off, granules;        // range = floats [off, off + 8*granules)
+    long long cost_idx;             // >= 0: g[cost_idx] is summed over the ranks in fp32 beside the range
+    int world, rank, wire_bf16, blocks;
+    unsigned char* peer[kMaxWorld]; // every rank's exchange block as mapped in this process (peer[rank] = the own block)
+    long long off_flag1, off_flag2; // unsigned [blocks][kMaxWorld]: flag of (workgroup, source rank)
+    long long off_cost;             // float [kMaxWorld]: the ranks' local costs
+    long long off_seq;              // unsigned [blocks]: calls completed by workgroup w (local use only)
+    long long off_err;              // unsigned: nonzero after a timed-out wait (local use only)
+    long long off_slots, slot_stride, off_res;   // bytes
+    unsigned long long timeout_ticks;            // of the 100 MHz wall clock
+};
+void launch_ipc_allreduce(const IpcArgs& a, hipStream_t s);
+// bf16 wire format for the RCCL path: gradient range -> bf16 wire buffer, and back after the all-reduce
+void launch_wire_pack(const float* g, void* wire, long long n, hipStream_t s);
+void launch_wire_unpack(float* g, const void* wire, long long n, hipStream_t s);
+
 // Diagnostic build only (-DAVAE_STAMPS): thread 0 of every block records s_memrealtime (100 MHz)
 // at kernel entry / after the item lookup / after the first staged tile / after the K loop / at
 // the end, plus s_memtime (shader clock) at entry and end.  No stamp executes in the product build.

@@ -188,8 +188,17 @@ struct avae_handle {
     std::vector<AdamItem> adam_items_b;     // [bucket 0 items ..., bucket 1 items ...], tile bases per bucket
     size_t off_adam_b = 0;
     // library-owned collective (RCCL): one communicator per replica, its own stream, events between the two streams
-    void* comm = nullptr;
+    void* comm = nullptr;                   // AVAE_COMM_RCCL: the ncclComm_t
     int comm_world = 1, comm_rank = 0;
+    bool comm_on = false;                   // a library-owned collective (either backend) is up
+    size_t off_wire = 0;                    // RCCL with bf16 on the wire: the packed gradient [P_int] bf16
+    // AVAE_COMM_IPC: this replica's exchange block (uncached device memory, exported to the peers), the peers' blocks as mapped here
+    unsigned char* ipc_block = nullptr;
+    size_t ipc_bytes = 0;
+    unsigned char* ipc_peer[kMaxWorld] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ipc_opened[kMaxWorld] = {false, false, false, false, false, false, false, false};
+    bool ipc_attached = false;
+    IpcArgs ipc_args{};                     // layout + peers; off / granules / cost_idx are filled per call
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_grad[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
     std::vector<hipGraphExec_t> g_dp[2];    // per staging set: captured segment of bucket b (forward + backward part + its weight gradients)
@@ -219,12 +228,16 @@ struct avae_handle {
     std::vector<Serve> serve;
     size_t off_slot = 0;
 
-    hipGraphExec_t g_full = nullptr, g_bwd = nullptr, g_eval = nullptr;
+    hipGraphExec_t g_full = nullptr, g_eval = nullptr;
     hipGraphExec_t g_multi[2] = {nullptr, nullptr};   // kMultiSizes[i] whole steps per replay (avae_train_steps)
     hipGraph_t g_full_graph = nullptr, g_multi_graph[2] = {nullptr, nullptr};   // templates, kept: their staging-kernel nodes are re-parameterised per replay
     hipGraphNode_t g_full_prep = nullptr, g_multi_prep[2] = {nullptr, nullptr};
-    std::vector<hipGraphExec_t> g_bwd_set;  // data-parallel runs: forward + backward + wgrad on staging set j (captured on first use)
 
+    // Calls on one handle share its activation buffers and serving slot: a call on a different stream than the previous one is
+    // ordered behind that one's work (an event recorded on the old stream when the switch is seen: nothing per call otherwise).
+    hipStream_t last_stream = nullptr;
+    bool has_last_stream = false;
+    hipEvent_t ev_switch = nullptr;
     unsigned draw_id = 0;                   // eval / reconstruct calls that drew their own eps (keys the generator: a fresh draw per call)
     bool timing = false;
     bool debug_sync = false;
@@ -278,6 +291,9 @@ void check_config(const avae_config& c) {
     if (c.batch_size < 1) throw Err("batch_size must be positive");
     if (c.compute_dtype != AVAE_F32 && c.compute_dtype != AVAE_BF16) throw Err("compute_dtype must be AVAE_F32 or AVAE_BF16");
     if (c.activation < AVAE_ACT_IDENTITY || c.activation > AVAE_ACT_TANH) throw Err("unknown activation");
+    if (c.comm_buckets != 0 && c.comm_buckets != 1 && c.comm_buckets != 2) throw Err("comm_buckets must be 0, 1 or 2");
+    if (c.wire_dtype != AVAE_F32 && c.wire_dtype != AVAE_BF16) throw Err("wire_dtype must be AVAE_F32 or AVAE_BF16");
+    if (c.use_comm < AVAE_COMM_NONE || c.use_comm > AVAE_COMM_IPC) throw Err("use_comm must be AVAE_COMM_NONE, AVAE_COMM_RCCL or AVAE_COMM_IPC");
     for (int m = 0; m < c.n_modalities; ++m) {
         const avae_modality& mo = c.mod[m];
         if (mo.n_input < 1) throw Err("n_input must be positive");
@@ -470,6 +486,7 @@ void plan_memory(avae_handle* h) {
     h->off_m = b.take(pint * 4);
     h->off_v = b.take(pint * 4);
     h->off_g = b.take((pint + 64) * 4);      // + cost slot (element P_int), padded
+    if (c.use_comm == AVAE_COMM_RCCL && c.wire_dtype == AVAE_BF16) h->off_wire = b.take((pint + 64) * 2);     // the gradient as it travels
     // cost partial slots: one per output-loss tile (the smallest tile, 32x32, bounds the count) + latent tiles
     int slots = (B + kLatentRows - 1) / kLatentRows;
     for (int m = 0; m < h->M; ++m) slots += ((B + 31) / 32) * ((h->mods[m].n_in + 31) / 32);
@@ -1478,7 +1495,7 @@ void build_training_plan(avae_handle* h) {
         }
     }
     // ---- small nets: the optimiser in the epilogue of the (single) weight-gradient launch.  Only for the plain single-replica step
-    // (under data parallelism the all-reduce sits between the two; avae_step_backward / avae_step_apply keep them apart as well).
+    // (under data parallelism the all-reduce sits between the two; avae_dp_backward / avae_dp_apply keep them apart as well).
     h->wgrad_adam.clear();
     if (!any_conv && h->wgrad.size() == 1 && h->wgrad[0].tn && h->wgrad[0].cfg == 0 && h->wgrad[0].targs.xcd_group == 1
         && !std::getenv("AVAE_NO_LEAN") && !std::getenv("AVAE_NO_ADAM_FUSE")) {
@@ -1897,7 +1914,6 @@ void init_device(avae_handle* h) {
     if (h->cfg.use_graph) {
         const bool tsave = h->timing;
         h->timing = false;
-        h->g_bwd = capture(h, [&](hipStream_t cs) { run_launches(h, h->fwd, cs); run_launches(h, h->bwd, cs); run_launches(h, h->wgrad, cs); });
         std::vector<const float*> x0(h->M, h->at<float>(h->mods[0].X32));    // placeholders, patched per step
         if (h->overlap && h->n_buckets == 2) {
             HIP_OK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
@@ -1970,26 +1986,30 @@ void init_device(avae_handle* h) {
     }
 }
 
-void do_backward(avae_handle* h, hipStream_t s) {
-    if (h->g_bwd && !h->timing) HIP_OK(hipGraphLaunch(h->g_bwd, s));
-    else { run_launches(h, h->fwd, s); run_launches(h, h->bwd, s); run_launches(h, h->wgrad, s); }
-}
-
-void do_apply(avae_handle* h, hipStream_t s) {
-    // one kernel: launched directly (a graph replay boundary costs ~5 us of idle GPU, a launch ~5 us of host time:
-    // C2 seam path 95.6 vs 101.2 us/step)
-    run_adam(h, 0, s);
-}
+void comm_check_error(avae_handle* h);
 
 void fetch_cost(avae_handle* h, float* cost_host, bool from_state, hipStream_t s) {
     if (!cost_host) return;
     const void* src = from_state ? (const void*)&h->state()->last_cost : (const void*)(h->grad() + h->P_int);
     HIP_OK(hipMemcpyAsync(cost_host, src, sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
+    comm_check_error(h);
 }
 
 void copy_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, hipStream_t s) {
     HIP_OK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, s));
+}
+
+// start of every stream-taking call (under the handle's mutex)
+hipStream_t on_stream(avae_handle* h, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (h->has_last_stream && s != h->last_stream) {
+        if (!h->ev_switch) HIP_OK(hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
+        if (hipEventRecord(h->ev_switch, h->last_stream) == hipSuccess) HIP_OK(hipStreamWaitEvent(s, h->ev_switch, 0));
+        else (void)hipGetLastError();          // the previous stream no longer exists: its work is done
+    }
+    h->last_stream = s; h->has_last_stream = true;
+    return s;
 }
 
 template <typename F> int guarded(avae_handle* h, F&& f) {
@@ -2052,11 +2072,33 @@ struct Rccl {
         int r_ = (expr);                                                                         \
         if (r_ != 0) throw Err(std::string(#expr) + ": " + (Rccl::get().err_str ? Rccl::get().err_str(r_) : "RCCL error") + " (" + std::to_string(r_) + ")"); \
     } while (0)
-constexpr int kNcclFloat32 = 7, kNcclSum = 0;        // rccl.h: ncclFloat32, ncclSum
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;        // rccl.h: ncclFloat32, ncclSum (ncclBfloat16 = 9)
 
-void comm_init(avae_handle* h) {
+constexpr int kNcclBfloat16 = 9;
+constexpr uint32_t kIpcMagic = 0x41564950u;      // "AVIP"
+struct IpcHandleBytes {                          // what avae_comm_ipc_handle hands out (AVAE_IPC_HANDLE_BYTES)
+    hipIpcMemHandle_t mem;                       // 64 bytes
+    uint64_t bytes, raw_ptr, layout;             // block size; the exporter's own pointer (same-process attach); layout check word
+    int32_t rank, world, pid;
+    uint32_t magic;
+};
+static_assert(sizeof(IpcHandleBytes) <= AVAE_IPC_HANDLE_BYTES, "IPC handle bytes");
+static_assert(kMaxWorld == AVAE_MAX_WORLD, "world size limit");
+
+void comm_streams(avae_handle* h) {
+    int lo = 0, hi = 0;                          // the collective's kernels should start the moment their gradients exist
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIP_OK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
+    for (int b = 0; b < 2; ++b) {
+        HIP_OK(hipEventCreateWithFlags(&h->ev_grad[b], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_red[b], hipEventDisableTiming));
+    }
+    h->comm_world = h->cfg.world_size; h->comm_rank = h->cfg.rank;
+    h->comm_on = true;
+}
+
+void comm_init_rccl(avae_handle* h) {
     Rccl& R = Rccl::get();
-    if (h->cfg.world_size < 1 || h->cfg.rank < 0 || h->cfg.rank >= h->cfg.world_size) throw Err("use_comm: world_size / rank out of range");
     Rccl::Id id;
     std::memcpy(id.b, h->cfg.nccl_id, 128);
     {   // RCCL prints a version banner on stdout when its first communicator comes up; the host's stdout may be a protocol
@@ -2069,11 +2111,64 @@ void comm_init(avae_handle* h) {
         if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
         NCCL_OK(rc);
     }
-    h->comm_world = h->cfg.world_size; h->comm_rank = h->cfg.rank;
-    HIP_OK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) {
-        HIP_OK(hipEventCreateWithFlags(&h->ev_grad[b], hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&h->ev_red[b], hipEventDisableTiming));
+    comm_streams(h);
+}
+
+// Exchange block of the one-shot all-reduce: [flag1 | flag2 | costs | seq | err | slots (one per source rank) | result area]
+void comm_init_ipc(avae_handle* h) {
+    const int N = h->cfg.world_size;
+    IpcArgs& a = h->ipc_args;
+    std::memset(&a, 0, sizeof(a));
+    int blocks = 64;
+    if (const char* e = std::getenv("AVAE_IPC_BLOCKS")) blocks = std::atoi(e);
+    if (blocks < 1 || blocks > 1024) throw Err("AVAE_IPC_BLOCKS out of range");
+    const bool bf = h->cfg.wire_dtype == AVAE_BF16;
+    const size_t gb = bf ? 16 : 32, G = h->P_int / 8, S = (G + N - 1) / N;        // (P_int is a multiple of 32 floats)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = rup(off + bytes, 256); return o; };
+    a.off_flag1 = (long long)take((size_t)blocks * kMaxWorld * 4);
+    a.off_flag2 = (long long)take((size_t)blocks * kMaxWorld * 4);
+    a.off_cost = (long long)take(kMaxWorld * 4);
+    a.off_seq = (long long)take((size_t)blocks * 4);
+    a.off_err = (long long)take(4);
+    a.slot_stride = (long long)rup(S * gb, 256);
+    a.off_slots = (long long)take((size_t)N * a.slot_stride);
+    a.off_res = (long long)take(G * gb);
+    h->ipc_bytes = off;
+    a.g = h->grad(); a.world = N; a.rank = h->cfg.rank; a.wire_bf16 = bf ? 1 : 0; a.blocks = blocks;
+    double ms = 20000.0;                          // a peer that is this late has failed: raise the error word instead of hanging
+    if (const char* e = std::getenv("AVAE_IPC_TIMEOUT_MS")) ms = std::atof(e);
+    a.timeout_ticks = (unsigned long long)(ms * 1e5);                             // 100 MHz wall clock
+    // uncached: neither this device's L2s nor a peer's keep lines of it (RCCL allocates its own buffers the same way)
+    HIP_OK(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->ipc_block), h->ipc_bytes, hipDeviceMallocUncached));
+    HIP_OK(hipMemset(h->ipc_block, 0, h->ipc_bytes));
+    HIP_OK(hipDeviceSynchronize());
+    a.peer[h->cfg.rank] = h->ipc_block; h->ipc_peer[h->cfg.rank] = h->ipc_block;
+    comm_streams(h);
+    h->ipc_attached = N == 1;
+}
+
+void comm_init(avae_handle* h) {
+    if (h->cfg.world_size < 1 || h->cfg.world_size > kMaxWorld || h->cfg.rank < 0 || h->cfg.rank >= h->cfg.world_size)
+        throw Err("use_comm: world_size must be in [1," + std::to_string(kMaxWorld) + "] and rank in [0, world_size)");
+    if (h->cfg.use_comm == AVAE_COMM_RCCL) comm_init_rccl(h);
+    else if (h->cfg.use_comm == AVAE_COMM_IPC) comm_init_ipc(h);
+    else throw Err("use_comm must be AVAE_COMM_NONE, AVAE_COMM_RCCL or AVAE_COMM_IPC");
+}
+
+uint64_t ipc_layout_word(const avae_handle* h) {
+    return (uint64_t)h->P_int * 1315423911ull ^ ((uint64_t)h->ipc_args.blocks << 48) ^ ((uint64_t)h->ipc_args.wire_bf16 << 40) ^ (uint64_t)h->ipc_bytes;
+}
+
+void comm_check_error(avae_handle* h) {       // after a synchronise: did a bounded wait of the IPC all-reduce give up?
+    if (!h->ipc_block) return;
+    unsigned e = 0;
+    HIP_OK(hipMemcpy(&e, h->ipc_block + h->ipc_args.off_err, 4, hipMemcpyDeviceToHost));
+    if (e) {
+        std::string who;
+        for (int r = 0; r < kMaxWorld; ++r) if (e & (1u << (8 + r))) who += " " + std::to_string(r);
+        throw Err("IPC all-reduce: timed out waiting for rank(s)" + who + " (phase mask " + std::to_string(e & 0xFFu) +
+                  "): a peer stopped, or the ranks did not make the same sequence of training calls");
     }
 }
 
@@ -2112,24 +2207,45 @@ void dp_segment(avae_handle* h, int j, int bucket, hipStream_t s, bool direct = 
     }
 }
 
+// SUM-all-reduce of bucket b's range of the gradient buffer on the comm stream (either backend)
+void dp_allreduce(avae_handle* h, int b, hipStream_t cs) {
+    const avae_handle::Range& r = h->ranges_b[b][0];
+    float* g = h->grad();
+    const bool has_cost = r.off + r.count == h->P_int + 1;
+    const size_t n = has_cost ? r.count - 1 : r.count;               // the gradient part: a multiple of 32 floats
+    Timed t(h, cs, h->n_buckets == 1 ? "allreduce" : b == 0 ? "allreduce_dec" : "allreduce_enc");
+    t_launch_events = LaunchEvents{nullptr, nullptr};               // (several enqueues: bracket them with plain records instead)
+    if (t.on) (void)hipEventRecord(t.a, cs);
+    if (h->cfg.use_comm == AVAE_COMM_IPC) {
+        if (!h->ipc_attached) throw Err("AVAE_COMM_IPC: avae_comm_ipc_attach has not been called on this replica");
+        IpcArgs a = h->ipc_args;
+        a.off = (long long)r.off; a.granules = (long long)(n / 8); a.cost_idx = has_cost ? (long long)h->P_int : -1;
+        launch_ipc_allreduce(a, cs);
+        LAUNCH_OK("ipc_allreduce");
+    } else {
+        Rccl& R = Rccl::get();
+        if (h->cfg.wire_dtype == AVAE_BF16) {                      // bf16 on the wire, the cost beside it in fp32
+            unsigned short* wire = h->at<unsigned short>(h->off_wire) + r.off;
+            launch_wire_pack(g + r.off, wire, (long long)n, cs); LAUNCH_OK("wire_pack");
+            NCCL_OK(R.group_start());
+            NCCL_OK(R.all_reduce(wire, wire, n, kNcclBfloat16, kNcclSum, h->comm, cs));
+            if (has_cost) NCCL_OK(R.all_reduce(g + h->P_int, g + h->P_int, 1, kNcclFloat32, kNcclSum, h->comm, cs));
+            NCCL_OK(R.group_end());
+            launch_wire_unpack(g + r.off, wire, (long long)n, cs); LAUNCH_OK("wire_unpack");
+        } else {
+            NCCL_OK(R.all_reduce(g + r.off, g + r.off, r.count, kNcclFloat32, kNcclSum, h->comm, cs));
+        }
+    }
+    if (t.on) (void)hipEventRecord(t.b, cs);
+}
+
 // one step of the library-owned data-parallel pipeline on staging set j (main stream s, collective on the comm stream)
 void dp_step(avae_handle* h, int j, hipStream_t s, bool direct = false) {
-    Rccl& R = Rccl::get();
-    float* g = h->grad();
     for (int b = 0; b < h->n_buckets; ++b) {
         dp_segment(h, j, b, s, direct);
         HIP_OK(hipEventRecord(h->ev_grad[b], s));
         HIP_OK(hipStreamWaitEvent(h->comm_stream, h->ev_grad[b], 0));
-        {
-            Timed t(h, h->comm_stream, b == 0 ? "allreduce_dec" : "allreduce_enc");
-            t_launch_events = LaunchEvents{nullptr, nullptr};      // (not a kernel launch of ours: bracket it with plain records instead)
-            if (t.on) (void)hipEventRecord(t.a, h->comm_stream);
-            NCCL_OK(R.group_start());
-            for (const avae_handle::Range& r : h->ranges_b[b])
-                NCCL_OK(R.all_reduce(g + r.off, g + r.off, r.count, kNcclFloat32, kNcclSum, h->comm, h->comm_stream));
-            NCCL_OK(R.group_end());
-            if (t.on) (void)hipEventRecord(t.b, h->comm_stream);
-        }
+        dp_allreduce(h, b, h->comm_stream);
         HIP_OK(hipEventRecord(h->ev_red[b], h->comm_stream));
     }
     for (int b = 0; b < h->n_buckets; ++b) {
@@ -2272,6 +2388,7 @@ int avae_create(const avae_config* cfg, avae_handle** out) {
         if (h) {
             if (h->comm) { try { (void)Rccl::get().destroy(h->comm); } catch (...) {} }
             if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+            if (h->ipc_block) (void)hipFree(h->ipc_block);
             if (h->own_ws && h->ws) (void)hipFree(h->ws);
             if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
             delete h;
@@ -2286,15 +2403,17 @@ void avae_destroy(avae_handle* h) {
     if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
-    for (hipGraphExec_t g : {h->g_full, h->g_multi[0], h->g_multi[1], h->g_bwd, h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
-    for (hipGraphExec_t g : h->g_bwd_set) if (g) (void)hipGraphExecDestroy(g);
+    for (hipGraphExec_t g : {h->g_full, h->g_multi[0], h->g_multi[1], h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
     for (int b = 0; b < 2; ++b) for (hipGraphExec_t g : h->g_dp[b]) if (g) (void)hipGraphExecDestroy(g);
     for (avae_handle::Serve& sv : h->serve) if (sv.graph) (void)hipGraphExecDestroy(sv.graph);
+    if (h->ev_switch) (void)hipEventDestroy(h->ev_switch);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     for (int gi = 0; gi < 2; ++gi) { if (h->g_dpm[gi]) (void)hipGraphExecDestroy(h->g_dpm[gi]); if (h->g_dpm_graph[gi]) (void)hipGraphDestroy(h->g_dpm_graph[gi]); }
     if (h->comm) { try { (void)Rccl::get().destroy(h->comm); } catch (...) {} }
+    for (int r = 0; r < kMaxWorld; ++r) if (h->ipc_opened[r] && h->ipc_peer[r]) (void)hipIpcCloseMemHandle(h->ipc_peer[r]);
+    if (h->ipc_block) (void)hipFree(h->ipc_block);
     for (int b = 0; b < 2; ++b) { if (h->ev_grad[b]) (void)hipEventDestroy(h->ev_grad[b]); if (h->ev_red[b]) (void)hipEventDestroy(h->ev_red[b]); }
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     for (hipGraph_t g : {h->g_full_graph, h->g_multi_graph[0], h->g_multi_graph[1]}) if (g) (void)hipGraphDestroy(g);
@@ -2351,28 +2470,12 @@ int avae_set_opt_state(avae_handle* h, const float* host_m, const float* host_v,
     });
 }
 
-int avae_step_backward(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, void* stream) {
-    return guarded(h, [&] {
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull /*train*/, s);
-        do_backward(h, s);
-    });
-}
-
-int avae_step_apply(avae_handle* h, float* cost_host, void* stream) {
-    return guarded(h, [&] {
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        do_apply(h, s);
-        fetch_cost(h, cost_host, true, s);
-    });
-}
-
 // Data-parallel runs of consecutive batches: one staging launch for up to kMultiSteps batches, then per step
 // backward on its staging set -> (caller's all-reduce) -> apply.
 int avae_stage_batches(avae_handle* h, int32_t n_steps, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, void* stream) {
     return guarded(h, [&] {
         if (n_steps < 1 || n_steps > kMultiSteps) throw Err("avae_stage_batches: n_steps must be in [1," + std::to_string(kMultiSteps) + "]");
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        hipStream_t s = on_stream(h, stream);
         const PrepArgs a = make_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, n_steps);
         Timed t(h, s, "prep");
         launch_prep(h->cfg.compute_dtype, a, s);
@@ -2380,30 +2483,9 @@ int avae_stage_batches(avae_handle* h, int32_t n_steps, const float* const* x_de
     });
 }
 
-int avae_step_backward_staged(avae_handle* h, int32_t j, void* stream) {
-    return guarded(h, [&] {
-        if (j < 0 || j >= kMultiSteps) throw Err("avae_step_backward_staged: staging set out of range");
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        auto body = [&](hipStream_t cs) {
-            for (const std::vector<Launch>* ls : {&h->fwd, &h->bwd, &h->wgrad}) {
-                std::vector<Launch> moved;
-                for (const Launch& L : *ls) moved.push_back(relocated(h, L, j));
-                run_launches(h, moved, cs);
-            }
-        };
-        if (h->cfg.use_graph && !h->timing) {
-            if (h->g_bwd_set.empty()) h->g_bwd_set.assign(kMultiSteps, nullptr);
-            if (!h->g_bwd_set[j]) h->g_bwd_set[j] = capture(h, body);
-            HIP_OK(hipGraphLaunch(h->g_bwd_set[j], s));
-        } else {
-            body(s);
-        }
-    });
-}
-
 // one single-replica step
 void train_one(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, hipStream_t s) {
-    if (h->comm) {                      // library-owned collective: stage, then the bucketed pipeline
+    if (h->comm_on) {                   // library-owned collective: stage, then the bucketed pipeline
         const PrepArgs a = make_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x7261696eull, 1);
         { Timed t(h, s, "prep"); launch_prep(h->cfg.compute_dtype, a, s); LAUNCH_OK("prep"); }
         dp_step(h, 0, s);
@@ -2427,7 +2509,7 @@ void train_one(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, c
 
 int avae_train_step(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, float* cost_host, void* stream) {
     return guarded(h, [&] {
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        hipStream_t s = on_stream(h, stream);
         train_one(h, x_dev, x_ld, eps_dev, s);
         fetch_cost(h, cost_host, true, s);
     });
@@ -2437,7 +2519,7 @@ int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev,
                      float* cost_host, void* stream) {
     return guarded(h, [&] {
         if (n_steps < 1) throw Err("avae_train_steps: n_steps must be >= 1");
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        hipStream_t s = on_stream(h, stream);
         std::vector<const float*> x(h->M);
         auto batch = [&](int i) {       // rows [i*B, (i+1)*B) of every modality and of eps
             for (int m = 0; m < h->M; ++m) {
@@ -2447,7 +2529,7 @@ int avae_train_steps(avae_handle* h, int32_t n_steps, const float* const* x_dev,
             return eps_dev ? eps_dev + (size_t)i * h->B * h->nz : nullptr;
         };
         int i = 0;
-        if (h->comm) {                  // data parallel: batches staged kMultiSteps at a time, then backward -> all-reduce -> Adam per bucket and step
+        if (h->comm_on) {               // data parallel: batches staged kMultiSteps at a time, then backward -> all-reduce -> Adam per bucket and step
             // Runs of 16 (then 4) steps as ONE captured graph -- staging kernel, segments, ncclAllReduce on the comm stream (it
             // joins the capture through the events), Adam per bucket -- so that the host is out of the loop exactly as in the
             // single-replica path.  If RCCL refuses capture on this stack the host steps the same pipeline.
@@ -2526,13 +2608,13 @@ int avae_dp_plan(const avae_config* cfg, int32_t* n_buckets, int32_t* n_ranges, 
 }
 
 int avae_dp_backward(avae_handle* h, int32_t j, int32_t bucket, void* stream) {
-    return guarded(h, [&] { dp_segment(h, j, bucket, reinterpret_cast<hipStream_t>(stream)); });
+    return guarded(h, [&] { dp_segment(h, j, bucket, on_stream(h, stream)); });
 }
 
 int avae_dp_apply(avae_handle* h, int32_t bucket, float* cost_host, void* stream) {
     return guarded(h, [&] {
         if (bucket < 0 || bucket >= h->n_buckets) throw Err("data-parallel bucket out of range");
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        hipStream_t s = on_stream(h, stream);
         run_adam(h, 0, s, h->n_buckets == 1 ? -1 : bucket);
         fetch_cost(h, cost_host, true, s);
     });
@@ -2546,10 +2628,49 @@ int avae_comm_unique_id(void* id128) {
     } catch (const std::exception& e) { g_create_error = e.what(); return 2; }
 }
 
+int avae_comm_ipc_handle(avae_handle* h, void* handle_out) {
+    return guarded(h, [&] {
+        if (!handle_out) throw Err("null argument");
+        if (!h->ipc_block) throw Err("avae_comm_ipc_handle: the replica was not created with use_comm = AVAE_COMM_IPC");
+        IpcHandleBytes hb;
+        std::memset(&hb, 0, sizeof(hb));
+        HIP_OK(hipIpcGetMemHandle(&hb.mem, h->ipc_block));
+        hb.bytes = h->ipc_bytes; hb.raw_ptr = reinterpret_cast<uint64_t>(h->ipc_block); hb.layout = ipc_layout_word(h);
+        hb.rank = h->cfg.rank; hb.world = h->cfg.world_size; hb.pid = (int32_t)getpid(); hb.magic = kIpcMagic;
+        std::memset(handle_out, 0, AVAE_IPC_HANDLE_BYTES);
+        std::memcpy(handle_out, &hb, sizeof(hb));
+    });
+}
+
+int avae_comm_ipc_attach(avae_handle* h, const void* handles_by_rank) {
+    return guarded(h, [&] {
+        if (!handles_by_rank) throw Err("null argument");
+        if (!h->ipc_block) throw Err("avae_comm_ipc_attach: the replica was not created with use_comm = AVAE_COMM_IPC");
+        if (h->ipc_attached && h->cfg.world_size > 1) throw Err("avae_comm_ipc_attach: already attached");
+        const unsigned char* raw = reinterpret_cast<const unsigned char*>(handles_by_rank);
+        for (int r = 0; r < h->cfg.world_size; ++r) {
+            IpcHandleBytes hb;
+            std::memcpy(&hb, raw + (size_t)r * AVAE_IPC_HANDLE_BYTES, sizeof(hb));
+            if (hb.magic != kIpcMagic || hb.rank != r || hb.world != h->cfg.world_size)
+                throw Err("avae_comm_ipc_attach: entry " + std::to_string(r) + " is not rank " + std::to_string(r) + "'s handle of this job");
+            if (hb.bytes != h->ipc_bytes || hb.layout != ipc_layout_word(h))
+                throw Err("avae_comm_ipc_attach: rank " + std::to_string(r) + " was built with a different model / wire type / AVAE_IPC_BLOCKS");
+            if (r == h->cfg.rank) continue;
+            void* ptr = nullptr;
+            if (hb.pid == (int32_t)getpid()) ptr = reinterpret_cast<void*>(hb.raw_ptr);          // a replica of this very process: its pointer is ours
+            else { HIP_OK(hipIpcOpenMemHandle(&ptr, hb.mem, hipIpcMemLazyEnablePeerAccess)); h->ipc_opened[r] = true; }
+            h->ipc_peer[r] = reinterpret_cast<unsigned char*>(ptr);
+            h->ipc_args.peer[r] = h->ipc_peer[r];
+        }
+        h->ipc_attached = true;
+    });
+}
+
 int avae_cost_history(avae_handle* h, int32_t n, float* host_dst, int64_t* last_step) {
     return guarded(h, [&] {
         if (n < 0 || n > kCostHist) throw Err("cost history request out of range");
         HIP_OK(hipDeviceSynchronize());
+        comm_check_error(h);
         std::vector<unsigned char> buf(sizeof(DevState));
         HIP_OK(hipMemcpy(buf.data(), h->state(), sizeof(DevState), hipMemcpyDeviceToHost));
         const DevState* st = reinterpret_cast<const DevState*>(buf.data());
@@ -2561,7 +2682,7 @@ int avae_cost_history(avae_handle* h, int32_t n, float* host_dst, int64_t* last_
 
 int avae_eval_cost(avae_handle* h, const float* const* x_dev, const int32_t* x_ld, const float* eps_dev, float* cost_host, void* stream) {
     return guarded(h, [&] {
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        hipStream_t s = on_stream(h, stream);
         // a fresh eps per call, as each sess.run of the reference draws one (vae_assoc.py:90,388-391): the draw counter keys it
         const unsigned long long draw = eps_dev ? 0ull : (unsigned long long)((++h->draw_id) & 0x3FFFFFu) << 34;
         run_prep_batch(h, x_dev, x_ld, eps_dev, h->B, 0x6576616cull /*eval*/ | draw, s);
@@ -2581,7 +2702,7 @@ int avae_encode(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld, int
     return guarded(h, [&] {
         if (m < 0 || m >= h->M) throw Err("modality index out of range");
         if (rows < 0) throw Err("rows must be >= 0");
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        hipStream_t s = on_stream(h, stream);
         const Mod& md = h->mods[m];
         const int ld = x_ld > 0 ? x_ld : md.n_in;
         const size_t nzb = (size_t)h->nz * 4;
@@ -2599,7 +2720,7 @@ int avae_decode(avae_handle* h, int32_t m, const float* z_dev, int32_t rows, flo
     return guarded(h, [&] {
         if (m < 0 || m >= h->M) throw Err("modality index out of range");
         if (rows < 0) throw Err("rows must be >= 0");
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        hipStream_t s = on_stream(h, stream);
         const Mod& md = h->mods[m];
         for (int r0 = 0; r0 < rows; r0 += h->B) {
             const int n = std::min(h->B, rows - r0);
@@ -2614,7 +2735,7 @@ int avae_generate(avae_handle* h, const float* z_dev, int32_t rows, float* const
     return guarded(h, [&] {
         if (rows < 0) throw Err("rows must be >= 0");
         if (!z_dev || !xhat_dev) throw Err("null argument");
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        hipStream_t s = on_stream(h, stream);
         bool any_conv = false;
         for (const Mod& md : h->mods) any_conv = any_conv || md.conv;
         if (any_conv || !h->cfg.use_graph || h->timing) {     // conv decoders (and the diagnostic modes) go modality by modality
@@ -2661,7 +2782,7 @@ int avae_reconstruct(avae_handle* h, int32_t m, const float* x_dev, int32_t x_ld
     return guarded(h, [&] {
         if (m < 0 || m >= h->M) throw Err("modality index out of range");
         if (rows < 0) throw Err("rows must be >= 0");
-        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        hipStream_t s = on_stream(h, stream);
         const Mod& md = h->mods[m];
         const int ld = x_ld > 0 ? x_ld : md.n_in;
         // a fresh eps per call and per modality, as each sess.run of the reference draws one (vae_assoc.py:423-424): the salt's
@@ -2746,7 +2867,7 @@ int avae_load(avae_handle* h, const char* path) {
 }
 
 int avae_synchronize(avae_handle* h) {
-    return guarded(h, [&] { HIP_OK(hipDeviceSynchronize()); });
+    return guarded(h, [&] { HIP_OK(hipDeviceSynchronize()); comm_check_error(h); });
 }
 
 int avae_timing_enable(avae_handle* h, int32_t on) {

@@ -36,16 +36,28 @@ class GradSync(object):
     def backend(self):
         return dist.get_backend(self.group)
 
-    def broadcast_bytes(self, data, n, src=0):
+    def _boot(self, t, device):
+        """bootstrap tensors live where the backend wants them: the MODEL's device under nccl (not torch's current one)"""
+        return t.to(device) if (self.backend == "nccl" and device is not None and str(device) != "cpu") else t
+
+    def broadcast_bytes(self, data, n, src=0, device=None):
         """rank `src`'s n bytes on every rank (bootstrap of the library's RCCL communicator: the ncclUniqueId)"""
         t = torch.zeros(n, dtype=torch.uint8)
         if self.rank == src:
             t = torch.tensor(list(bytes(data)), dtype=torch.uint8)
         if self.world_size > 1:
-            if self.backend == "nccl":
-                t = t.cuda()
+            t = self._boot(t, device)
             dist.broadcast(t, src=src, group=self.group)
         return bytes(t.cpu().tolist())
+
+    def all_gather_bytes(self, data, n, device=None):
+        """every rank's n bytes, concatenated in rank order (bootstrap of the hipIpc exchange: the exported block handles)"""
+        mine = self._boot(torch.tensor(list(bytes(data)), dtype=torch.uint8), device)
+        if self.world_size == 1:
+            return bytes(data)
+        out = [torch.zeros_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(out, mine, group=self.group)
+        return b"".join(bytes(t.cpu().tolist()) for t in out)
 
     def all_reduce_ranges_(self, flat, ranges, async_op=False):
         """In-place SUM all-reduce of the (offset, count) float ranges of one bucket of the flat gradient buffer."""
@@ -68,14 +80,17 @@ class GradSync(object):
         self.all_reduce_(t)
         return float(t.item())
 
-    def broadcast_int(self, value, src=0):
+    def broadcast_int(self, value, src=0, device=None):
         """rank `src`'s integer on every rank (train(): one NumPy seed for the shuffles of all ranks)"""
         t = torch.tensor([int(value)], dtype=torch.int64)
         if self.world_size > 1:
-            if dist.get_backend(self.group) == "nccl":
-                t = t.cuda()
+            t = self._boot(t, device)
             dist.broadcast(t, src=src, group=self.group)
         return int(t.item())
+
+    def all_agree(self, ok, device):
+        """True on every rank iff `ok` on every rank (so that all ranks raise -- or none does)"""
+        return self.sum_scalar(1.0 if ok else 0.0, device) >= self.world_size
 
     def local_rows(self, batch_local):
         """Row range of this rank inside the global batch."""

@@ -95,15 +95,24 @@ class AssocVariationalAutoEncoder(object):
       use_graph      replay the step as a captured hipGraph
       data_parallel  True -> one replica per torch.distributed rank, sample-sharded batch, the gradient SUM-all-reduced per
                      step in two buckets (decoder side first, overlapping the encoder's backward pass), Adam per bucket
-      comm           who owns that collective: 'library' = libavae's own RCCL communicator (ncclAllReduce on the library's
-                     streams; torch.distributed only hands the ncclUniqueId round), 'torch' = torch.distributed all_reduce over
-                     the same buckets; None = 'library' when the process group's backend is nccl, else 'torch' (gloo tests).
-                     comm='library' without data_parallel builds a one-rank communicator (tests)
+      comm           who runs that collective:
+                       'ipc'     libavae's own one-shot all-reduce over hipIpc peers (push reduce-scatter + push all-gather, every
+                                 xGMI link at once; torch.distributed only hands the exchange-block handles round);
+                       'library' libavae's RCCL communicator (ncclAllReduce on the library's comm stream; torch.distributed only
+                                 hands the ncclUniqueId round);
+                       'torch'   torch.distributed.all_reduce over the same buckets, the host stepping the pipeline.
+                     None = 'torch' for world > 1 (the path every multi-rank parity test runs; pass 'ipc' / 'library' to opt in --
+                     bench.py does), 'torch' for one rank.  comm='library' / 'ipc' without data_parallel builds a one-rank
+                     communicator (tests)
+      comm_buckets   2 (default): decoder-side bucket first, its all-reduce beside the encoder's backward pass; 1: ONE all-reduce of
+                     the whole gradient buffer after the backward pass (north_star's literal design)
+      wire_dtype     'fp32' (default) or 'bf16': element type of the gradient on the wire (the cost always travels as fp32)
     """
 
     def __init__(self, network_architectures, binary=True, transfer_fct="softplus", weights=1.0,
                  assoc_lambda=1.0, learning_rate=0.001, batch_size=100, *, compute_dtype="bf16",
-                 device=None, seed=0, use_graph=True, data_parallel=False, process_group=None, comm=None):
+                 device=None, seed=0, use_graph=True, data_parallel=False, process_group=None, comm=None,
+                 comm_buckets=2, wire_dtype="fp32"):
         self.network_architectures = network_architectures
         self.assoc_lambda = assoc_lambda
         n_mod = len(network_architectures)
@@ -142,11 +151,17 @@ class AssocVariationalAutoEncoder(object):
         self._sync = GradSync(process_group) if data_parallel else None
         world = self._sync.world_size if self._sync else 1
         rank = self._sync.rank if self._sync else 0
-        if comm not in (None, "library", "torch"):
-            raise ValueError("comm must be None, 'library' or 'torch'")
+        if comm not in (None, "library", "torch", "ipc"):
+            raise ValueError("comm must be None, 'library', 'ipc' or 'torch'")
         if comm is None:
-            comm = "library" if (self._sync is not None and self._sync.backend == "nccl") else "torch"
-        self._comm_lib = comm == "library"
+            comm = "torch"
+        if comm_buckets not in (1, 2):
+            raise ValueError("comm_buckets must be 1 or 2")
+        if wire_dtype not in _capi.DTYPE_IDS:
+            raise ValueError("wire_dtype must be 'fp32' or 'bf16'")
+        self._comm = comm
+        self._comm_lib = comm in ("library", "ipc")
+        self._wire_bf16 = _capi.DTYPE_IDS[wire_dtype] == 1
 
         cfg = _capi.Config()
         cfg.abi_version = _capi.AVAE_ABI_VERSION
@@ -182,9 +197,12 @@ class AssocVariationalAutoEncoder(object):
         cfg.beta1 = cfg.beta2 = cfg.adam_eps = 0.0          # -> TF-1 AdamOptimizer defaults
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
 
+        cfg.comm_buckets = comm_buckets
+        cfg.wire_dtype = _capi.DTYPE_IDS[wire_dtype]
         L = _capi.lib()
         agree_dev = self.device if (self._sync is not None and self._sync.backend == "nccl") else "cpu"
-        if self._comm_lib and world > 1:
+        self._agree_dev = agree_dev
+        if self._comm == "library" and world > 1:
             # ncclCommInitRank below is collective: a rank that cannot even load RCCL would leave the others waiting inside it.  Every
             # rank therefore probes the loader first (drawing an id is the cheapest call that needs it) and the ranks agree: all, or
             # the torch.distributed collective on the same buckets for everybody.
@@ -193,24 +211,23 @@ class AssocVariationalAutoEncoder(object):
             if self._sync.sum_scalar(ok, agree_dev) < world:
                 if rank == 0:
                     print("[vae_assoc_amd] RCCL cannot be loaded on every rank: gradient all-reduce through torch.distributed")
-                self._comm_lib = False
-        if self._comm_lib:
+                self._comm, self._comm_lib = "torch", False
+        if self._comm == "library":
             # bootstrap only: rank 0 draws the ncclUniqueId, torch.distributed hands it round; the communicator itself is the library's
             idb = (C.c_uint8 * 128)()
             if rank == 0:
                 _capi.check(None, L.avae_comm_unique_id(idb), "avae_comm_unique_id")
-            raw = self._sync.broadcast_bytes(bytes(idb), 128) if self._sync is not None else bytes(idb)
-            cfg.use_comm, cfg.world_size, cfg.rank = 1, world, rank
+            raw = self._sync.broadcast_bytes(bytes(idb), 128, device=agree_dev) if self._sync is not None else bytes(idb)
+            cfg.use_comm, cfg.world_size, cfg.rank = _capi.COMM_RCCL, world, rank
             for i in range(128):
                 cfg.nccl_id[i] = raw[i]
+        elif self._comm == "ipc":
+            cfg.use_comm, cfg.world_size, cfg.rank = _capi.COMM_IPC, world, rank
         # data-parallel buckets (host-only query): [[(offset, count), ...] per bucket]
         nb, nr = C.c_int32(0), (C.c_int32 * 2)()
-        offs, cnts = (C.c_int64 * (2 * _capi.AVAE_MAX_MODALITIES))(), (C.c_int64 * (2 * _capi.AVAE_MAX_MODALITIES))()
+        offs, cnts = (C.c_int64 * 2)(), (C.c_int64 * 2)()
         _capi.check(None, L.avae_dp_plan(C.byref(cfg), C.byref(nb), nr, offs, cnts), "avae_dp_plan")
-        self._buckets, k = [], 0
-        for b in range(nb.value):
-            self._buckets.append([(int(offs[k + i]), int(cnts[k + i])) for i in range(nr[b])])
-            k += nr[b]
+        self._buckets = [[(int(offs[b]), int(cnts[b]))] for b in range(nb.value)]      # ONE contiguous range per bucket
         nbytes = C.c_size_t(0)
         _capi.check(None, L.avae_workspace_bytes(C.byref(cfg), C.byref(nbytes)), "avae_workspace_bytes")
         # PyTorch is the device allocator: one uint8 tensor holds the whole replica state
@@ -224,15 +241,29 @@ class AssocVariationalAutoEncoder(object):
         torch.cuda.synchronize(self.device)
         rc = L.avae_create(C.byref(cfg), C.byref(h))
         if self._comm_lib and world > 1:
-            # a communicator that came up on some ranks only is of no use to any: agree, and fall back together
-            if self._sync.sum_scalar(1.0 if rc == 0 else 0.0, agree_dev) < world:
+            # Bring-up is agreed between the ranks at every collective step: a communicator / exchange that came up on some ranks
+            # only is of no use to any.  RCCL: ncclCommInitRank ran inside avae_create.  IPC: every rank that created its replica
+            # exports its exchange block, the handles go round (all_gather), every rank maps its peers' blocks.
+            ok = 1.0 if rc == 0 else 0.0
+            all_ok = self._sync.sum_scalar(ok, agree_dev) >= world
+            if all_ok and self._comm == "ipc":
+                mine = (C.c_uint8 * _capi.AVAE_IPC_HANDLE_BYTES)()
+                ok = 1.0 if L.avae_comm_ipc_handle(h, mine) == 0 else 0.0
+                blob = self._sync.all_gather_bytes(bytes(mine), _capi.AVAE_IPC_HANDLE_BYTES, device=agree_dev)
+                if ok:
+                    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+                    ok = 1.0 if L.avae_comm_ipc_attach(h, buf) == 0 else 0.0
+                    if not ok:
+                        print("[vae_assoc_amd] rank %d: %s" % (rank, L.avae_last_error(h).decode("utf-8", "replace")))
+                all_ok = self._sync.sum_scalar(ok, agree_dev) >= world
+            if not all_ok:
                 if rc == 0:
                     L.avae_destroy(h)
                 if rank == 0:
-                    print("[vae_assoc_amd] the library's RCCL communicator did not come up on every rank: gradient all-reduce "
-                          "through torch.distributed")
-                self._comm_lib = False
-                cfg.use_comm = 0
+                    print("[vae_assoc_amd] the library's %s collective did not come up on every rank: gradient all-reduce "
+                          "through torch.distributed" % ("RCCL" if self._comm == "library" else "hipIpc"))
+                self._comm, self._comm_lib = "torch", False
+                cfg.use_comm = _capi.COMM_NONE
                 h = C.c_void_p()
                 rc = L.avae_create(C.byref(cfg), C.byref(h))
         _capi.check(None, rc, "avae_create")
@@ -349,9 +380,16 @@ class AssocVariationalAutoEncoder(object):
 
     # ------------------------------------------------------------------ data-parallel seam (parallel.py protocol)
     def _backward(self, X, eps=None):
-        ts, ptrs, lds, e = self._batch_args(X, eps)
-        _capi.check(self._h, self._L.avae_step_backward(self._h, ptrs, lds, e.data_ptr() if e is not None else None,
-                                                        self._stream()), "avae_step_backward")
+        """local forward + backward + every weight gradient: the gradient buffer (and the local cost in its last float) is complete"""
+        self._stage(X, eps)
+        for b in range(len(self._buckets)):
+            self._backward_bucket(b)
+
+    def _apply(self, want_cost=True):
+        cost = None
+        for b in range(len(self._buckets)):
+            cost = self._apply_bucket(b, want_cost and b == len(self._buckets) - 1)
+        return cost
 
     def _grad_tensor(self):
         return self._grad_view
@@ -369,12 +407,6 @@ class AssocVariationalAutoEncoder(object):
     def _apply_bucket(self, b, want_cost=True):
         cost = C.c_float(0.0)
         _capi.check(self._h, self._L.avae_dp_apply(self._h, b, C.byref(cost) if want_cost else None, self._stream()), "avae_dp_apply")
-        return cost.value if want_cost else None
-
-    def _apply(self, want_cost=True):
-        cost = C.c_float(0.0)
-        _capi.check(self._h, self._L.avae_step_apply(self._h, C.byref(cost) if want_cost else None, self._stream()),
-                    "avae_step_apply")
         return cost.value if want_cost else None
 
     # ------------------------------------------------------------------ reference surface
@@ -576,11 +608,19 @@ def train_loop(vae_assoc, data_sets, network_architectures, batch_size, training
     batch_global = batch_size * world
     lo, hi = rank * batch_size, (rank + 1) * batch_size
     if world > 1:
-        np.random.seed(sync.broadcast_int(int(np.random.randint(0, 2 ** 31 - 1))))
+        boot_dev = getattr(vae_assoc, "_agree_dev", "cpu" if dev is None else dev)
+        np.random.seed(sync.broadcast_int(int(np.random.randint(0, 2 ** 31 - 1)), device=boot_dev))
+        # every rank must hold the SAME training matrix in the SAME order: rank 0's digest of ~256 sampled rows (content and
+        # position both enter) goes round, every rank compares its own with it, and the verdicts are all-reduced so that either
+        # every rank raises or none does (a rank that raised alone would leave the others waiting in the next collective)
         d = data_sets.train._data
-        probe = d[:: max(1, n_samples // 64)]
-        chk = float(probe.double().sum().item()) if torch.is_tensor(probe) else float(np.asarray(probe, dtype=np.float64).sum())
-        if abs(sync.sum_scalar(chk, "cpu" if dev is None else dev) - world * chk) > 1e-6 * max(1.0, abs(world * chk)):
+        rows = d[:: max(1, n_samples // 256)]
+        rows = rows.double().cpu().numpy() if torch.is_tensor(rows) else np.asarray(rows, dtype=np.float64)
+        wts = np.cos(np.arange(rows.size, dtype=np.float64).reshape(rows.shape) * 0.7548776662466927)
+        digest = np.array([n_samples, rows.shape[1], float((rows * wts).sum()), float(np.abs(rows).sum())], dtype=np.float64)
+        ref = np.frombuffer(sync.broadcast_bytes(digest.tobytes(), digest.nbytes, device=boot_dev), dtype=np.float64)
+        same = bool(np.all(np.abs(ref - digest) <= 1e-9 * np.maximum(1.0, np.abs(ref))))
+        if not sync.all_agree(same, boot_dev):
             raise ValueError("data_parallel train(): the ranks hold different training matrices (or different orders of one); "
                              "build the data sets from the same array with the same NumPy seed on every rank")
 
