@@ -260,7 +260,7 @@ def cpu_baseline(archs, B, budget_s=10.0):
 GEMM_LAUNCH_PREFIXES = ("fwd_enc", "fwd_dec", "fwd_head", "fwd_out_loss", "bwd_", "wgrad", "conv_enc", "conv_dec", "conv_bwd")
 
 
-def measure(name, args, world, rank, local_rank, steps, warmup, repeats, kernel_steps, dtype=None):
+def measure(name, args, world, rank, local_rank, steps, warmup, repeats, kernel_steps, dtype=None, comm=None, wire=None, local_only=False):
     """Builds the model of config `name`, times `repeats` x `steps` train steps (each repeat bracketed by barrier +
     synchronise; MAX over ranks per repeat), then one eager pass with per-launch HIP events.  Returns a dict."""
     import torch
@@ -269,9 +269,12 @@ def measure(name, args, world, rank, local_rank, steps, warmup, repeats, kernel_
     archs, B, cfg_dtype, label = CONFIGS[name]
     dtype = dtype or cfg_dtype
     es = 2 if dtype == "bf16" else 4
+    comm = comm if comm is not None else ((args.comm if args.comm != "auto" else "ipc") if (args.force_comm and world == 1) else None)
     model = AssocVariationalAutoEncoder(archs, transfer_fct="relu", batch_size=B, compute_dtype=dtype, device=local_rank,
-                                        seed=0, use_graph=not args.no_graph, data_parallel=world > 1,
-                                        comm="library" if (args.force_comm and world == 1) else None, **hyper_for(archs))
+                                        seed=0, use_graph=not args.no_graph, data_parallel=world > 1 and not local_only,
+                                        comm=comm, comm_buckets=args.comm_buckets, wire_dtype=wire or args.wire, **hyper_for(archs))
+    if world > 1 and not local_only:
+        assert model._comm == comm, "the %s collective did not come up (fell back to %s)" % (comm, model._comm)
     # resident synthetic data: 16 batches per rank (rank r owns global rows [r*B, (r+1)*B) of each global batch)
     nb = 16
     rng = np.random.default_rng(20260104 + rank)
@@ -285,6 +288,8 @@ def measure(name, args, world, rank, local_rank, steps, warmup, repeats, kernel_
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    if local_only:                       # a one-rank measurement inside a multi-rank job: no cross-rank barriers, no MAX
+        world = 1
 
     def run(n):
         """n train steps over the resident batches in order (eps: in-kernel Philox stream).  A single replica
@@ -349,11 +354,68 @@ def measure(name, args, world, rank, local_rank, steps, warmup, repeats, kernel_
             kern[base] = (max(c0, int(calls)), a0 + float(avg_ms), m0 + float(min_ms))
     if world > 1:
         barrier()
+    model.synchronize()                  # (raises if a bounded wait of the hipIpc all-reduce gave up)
     res = {"name": name, "label": label, "B": B, "dtype": dtype, "es": es, "archs": archs, "dt": dt, "dts": dts, "steps": steps,
-           "kern": kern, "last_cost": last_cost, "pcie": pcie, "n_params": int(model.n_params)}
+           "kern": kern, "last_cost": last_cost, "pcie": pcie, "n_params": int(model.n_params), "comm": model._comm,
+           "buckets": len(model._buckets), "wire": wire or args.wire}
     del model, data, batches, whole
     torch.cuda.empty_cache()
     return res
+
+
+def choose_comm(args, world, rank, local_rank):
+    """N > 1: the fastest collective that reproduces torch.distributed's result on THIS node.  Every candidate trains the bench
+    model for a few steps (single steps and a captured run) from the same weights, on the same batches and eps stream as a
+    torch.distributed reference, and must land on the same weights; the ranks agree on the verdict, so they switch together."""
+    import torch
+    import torch.distributed as dist
+    from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+    if args.comm != "auto":
+        return args.comm, ["--comm %s" % args.comm]
+    archs, B, cfg_dtype, _ = CONFIGS[args.config]
+    dtype = args.dtype or cfg_dtype
+    rng = np.random.default_rng(7 + rank)
+    mat, edges = synth_for(rng, archs, 20 * B)
+    data = torch.as_tensor(mat).cuda()
+    whole = [data[:, edges[k]:edges[k + 1]] for k in range(len(archs))]
+    os.environ.setdefault("AVAE_IPC_TIMEOUT_MS", "10000")
+
+    def trial(comm):
+        m = AssocVariationalAutoEncoder(archs, transfer_fct="relu", batch_size=B, compute_dtype=dtype, device=local_rank, seed=0,
+                                        use_graph=not args.no_graph, data_parallel=True, comm=comm, comm_buckets=args.comm_buckets,
+                                        wire_dtype="fp32", **hyper_for(archs))
+        if m._comm != comm:
+            raise RuntimeError("did not come up")
+        for i in range(2):
+            m.partial_fit([w[i * B:(i + 1) * B] for w in whole], return_cost=False)
+        m.partial_fit_steps([w[2 * B:] for w in whole], 18, return_cost=False)
+        m.synchronize()
+        return m.get_params(), m.cost_history(20).copy()
+
+    def agree(ok):
+        t = torch.tensor([1.0 if ok else 0.0], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    log = []
+    ref = trial("torch")
+    for cand in ("ipc", "library"):
+        ok, why = True, "matches torch.distributed"
+        try:
+            p, c = trial(cand)
+            dp, dc = float(np.abs(p - ref[0]).max()), float((np.abs(c - ref[1]) / np.abs(ref[1])).max())
+            # (only the order of the N-term fp32 sum differs: rounding-level gradient differences, amplified by Adam on the
+            # ill-conditioned elements and, with bf16 operands, by one-ulp flips of the weight shadows; a broken collective is O(1) off)
+            ok = bool(np.isfinite(p).all()) and dp <= (5e-4 if dtype == "fp32" else 5e-3) and dc <= (1e-4 if dtype == "fp32" else 1e-3)
+            if not ok:
+                why = "differs from torch.distributed: max|dtheta| %.2e, cost rel %.2e" % (dp, dc)
+        except Exception as e:
+            ok, why = False, repr(e)[:160]
+        all_ok = agree(ok)
+        log.append("%s: %s%s" % (cand, why, "" if all_ok or not ok else " (another rank failed)"))
+        if all_ok:
+            return cand, log
+    return "torch", log
 
 
 def price(res):
@@ -366,11 +428,16 @@ def price(res):
             kern[whole] = (max(kern[n][0] for n in parts), sum(kern[n][1] for n in parts), sum(kern[n][2] for n in parts))
     peak_tf = MFMA_BF16_PEAK_TF if es == 2 else MFMA_F32_PEAK_TF
     work, P = launch_work(archs, B, es)
-    for n in list(kern):                  # "a+b": launch b rides in launch a as its tail product (avae_host.hip::fuse_tail)
+    unfused = {}
+    for n in list(kern):                  # "a+b": launch b rides in launch a (tail product, avae_host.hip::fuse_tail; Adam in the wgrad epilogue)
         parts = n.split("+")
         if len(parts) > 1 and all(p in work for p in parts):
             vals = [work.pop(p) for p in parts]
-            work[n] = (sum(v[0] for v in vals), sum(v[1] for v in vals))
+            by = sum(v[0] for v in vals)
+            unfused[n] = by               # the sum of the parts: what the launches moved BEFORE they were fused
+            if parts == ["wgrad", "adam"]:
+                by -= 4 * P               # the fused launch stores the gradient but never re-reads it: a launch is priced on what it must move
+            work[n] = (by, sum(v[1] for v in vals))
     names = [n for n in kern if n in work]
     step_us = dt / steps * 1e6
     dom = max(names, key=lambda n: kern[n][1]) if names else None
@@ -385,8 +452,10 @@ def price(res):
         else:
             ach = by / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+        if dom in unfused and unfused[dom] != by:
+            roof["frac_unfused_accounting"] = round(unfused[dom] / avg_s / 1e9 / HBM_PEAK_GBS, 4)      # round 2's pricing (sum of the parts)
         traffic, src = None, None        # HBM bytes per launch from committed rocprofv3 --pmc passes of the builder (tools/pmc_traffic.sh)
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, res["name"]))
             if os.path.exists(tf):
                 traffic = json.load(open(tf))["launches"].get(dom, {}).get("hbm_bytes")
@@ -427,6 +496,12 @@ def main():
     ap.add_argument("--force-comm", action="store_true",
                     help="one GPU: run the step through the library's data-parallel pipeline (one-rank RCCL communicator, two buckets, "
                          "comm stream) to see what the pipeline itself costs; not the headline")
+    ap.add_argument("--comm", default="auto", choices=["auto", "ipc", "library", "torch"],
+                    help="N > 1: who runs the gradient all-reduce.  auto = the library's one-shot all-reduce over hipIpc peers, checked "
+                         "against torch.distributed on a few steps first; falls back to the library's RCCL communicator, then to "
+                         "torch.distributed, if the check fails on any rank")
+    ap.add_argument("--comm-buckets", type=int, default=2, choices=[1, 2], help="2: decoder bucket first (overlap); 1: one all-reduce of the whole buffer")
+    ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"], help="gradient element type on the wire (headline: fp32)")
     ap.add_argument("--host-input", action="store_true",
                     help="also time the step fed from pinned host batches (PCIe-inclusive rate; reported beside `value`, never as it)")
     args = ap.parse_args()
@@ -443,12 +518,44 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    # Rehearsal of the N > 1 path on a ONE-GPU box (AVAE_BENCH_ONE_GPU=1): every rank on cuda:0, gloo for the bootstrap -- RCCL refuses
+    # two ranks on one device, the hipIpc all-reduce does not.  The line says so ("rehearsal"); it is not a scaling measurement.
+    one_gpu = world > 1 and os.environ.get("AVAE_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    res = measure(args.config, args, world, rank, local_rank, args.steps, args.warmup, args.repeats, args.kernel_steps, args.dtype)
+    comm, comm_log = None, []
+    if world > 1:
+        comm, comm_log = choose_comm(args, world, rank, local_rank)
+    res = measure(args.config, args, world, rank, local_rank, args.steps, args.warmup, args.repeats, args.kernel_steps, args.dtype, comm=comm)
+    coll = None
+    if world > 1:
+        coll = {"backend": res["comm"], "buckets": res["buckets"], "wire": res["wire"], "selection": comm_log}
+        try:    # the same pipeline on one rank (split weight-gradient / Adam launches, the collective's launch, nothing on the wire):
+                # what is left of the N-rank step beyond it is the exposed, non-overlapped share of the collective
+            lo = measure(args.config, args, world, rank, local_rank, max(64, args.steps // 4), 32, 3, 0, args.dtype,
+                         comm="ipc" if res["comm"] == "ipc" else "library", local_only=True)
+            coll["pipeline_one_rank_ms_per_step"] = round(lo["dt"] / lo["steps"] * 1e3, 5)
+            coll["exposed_us_per_step"] = round((res["dt"] / res["steps"] - lo["dt"] / lo["steps"]) * 1e6, 2)
+        except Exception as e:
+            coll["pipeline_one_rank_error"] = repr(e)[:200]
+        if res["comm"] != "torch" and args.wire == "fp32":
+            try:    # bf16 on the wire, beside the headline (never as it)
+                wb = measure(args.config, args, world, rank, local_rank, max(64, args.steps // 4), 32, 3, 0, args.dtype, comm=res["comm"], wire="bf16")
+                coll["wire_bf16"] = {"ms_per_step": round(wb["dt"] / wb["steps"] * 1e3, 5), "value": round(wb["B"] * world * wb["steps"] / wb["dt"], 1),
+                                     "last_cost": wb["last_cost"]}
+            except Exception as e:
+                coll["wire_bf16"] = {"error": repr(e)[:200]}
+        for k in ("allreduce_dec", "allreduce_enc", "allreduce"):
+            if k in res["kern"]:
+                coll[k + "_us"] = round(res["kern"][k][1] * 1e3, 2)       # eager pass; includes waiting for the slowest peer
     extras = {}
     if world == 1 and not args.no_extras and args.config == "c2":
         # the other configurations of BASELINE.json on the same path, witnessed by the same run (short: they are parity-test
@@ -481,7 +588,10 @@ def main():
             "dtype": res["dtype"], "data": "synthetic",
             "config": {"workload": res["label"], "global_batch": B * world, "per_gpu_batch": B, "n_params": pr["n_params"] or res["n_params"],
                        "parallelism": "dp%d" % world, "graph": not args.no_graph,
-                       "collective": ("library-owned RCCL communicator, 2 buckets, all-reduce of the decoder bucket beside the encoder's backward pass"
+                       "collective": ("%s, %d bucket(s), %s on the wire" % ({"ipc": "library-owned one-shot all-reduce over hipIpc peers",
+                                                                                   "library": "library-owned RCCL communicator",
+                                                                                   "torch": "torch.distributed all_reduce, host-stepped"}[res["comm"]],
+                                                                                  res["buckets"], res["wire"])
                                       if (world > 1 or args.force_comm) else "none (one replica)"),
                        "submission": "per step" if args.single_step else "runs of <=16 consecutive resident batches"},
             "timing": {"repeats": args.repeats, "statistic": "median of the repeats, each EXACTLY --steps steps between barrier + synchronise",
@@ -493,6 +603,10 @@ def main():
             "launch_order": [n for n in res["kern"] if n not in ("prep", "_null_kernel")],      # one step's launches in issue order (tools/per_launch.py)
             "last_cost": res["last_cost"],
         }
+        if coll:
+            out["collective"] = coll
+            if one_gpu:
+                out["rehearsal"] = "%d ranks sharing ONE GPU (gloo bootstrap): exercises the N > 1 code path, not a scaling measurement" % world
         if extras:
             out.update(extras)
         if res["pcie"]:

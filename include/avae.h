@@ -200,7 +200,8 @@ int avae_synchronize(avae_handle* h);
  * one-store kernel timed the same way.  Report: one line "<name> <calls> <avg_ms> <min_ms>" per launch. */
 int avae_timing_enable(avae_handle* h, int32_t on);
 int avae_timing_report(avae_handle* h, char* buf, size_t buf_bytes);
-/* Copies a named internal fp32 tensor to the host (tests): "mulv<m>" [batch,2*n_z], "eps" [batch,n_z]. */
+/* Copies a named internal tensor to the host as fp32 (tests): "mulv<m>" [batch,2*n_z], "eps" [batch,n_z], "E<m>_<k>" / "D<m>_<k>" the
+ * stored output of encoder / decoder hidden layer k of modality m [batch, width] (the last forward pass's relu decisions). */
 int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t max_floats, size_t* n_floats);
 
 #ifdef __cplusplus

@@ -456,16 +456,22 @@ def shard_cost(archs, fw, X, binary, weights, assoc_lambda, batch_global):
 
 
 # ----------------------------------------------------------------------------- backward
-def backward(archs, params, fw, X, eps, binary, weights, assoc_lambda, act, batch_global=None, quant=None):
+def backward(archs, params, fw, X, eps, binary, weights, assoc_lambda, act, batch_global=None, quant=None, masks=None):
     """Analytic gradient of ``cost`` w.r.t. every parameter (what TF autodiff of
     vae_assoc.py:373-374 produces).  Formulas: SURVEY.md 8(a) row A5.  Mean terms carry
-    1/batch_global, sum terms (Gaussian recon, assoc) carry 1."""
+    1/batch_global, sum terms (Gaussian recon, assoc) carry 1.
+
+    ``masks`` (tests only, relu): ``masks[m]["enc"|"dec"][i]`` = boolean [B, width] "this hidden unit was active" decisions of
+    ANOTHER run of the same forward pass (the HIP path's stored activations > 0).  A relu pre-activation within rounding of 0
+    gets opposite decisions from two arithmetic types; with the decisions handed over, what is compared is the arithmetic."""
     _, dact_pre = ACT[act]
     q = _q(quant)
     if quant is None:
         dact = dact_pre
     else:
         dact = lambda a, y: DACT_FROM_OUTPUT[act](y)      # noqa: E731  (from the stored, rounded output)
+    if masks is not None and act != "relu":
+        raise ValueError("masks are relu decisions")
     M = len(archs)
     B = X[0].shape[0]
     Bg = B if batch_global is None else batch_global
@@ -500,7 +506,8 @@ def backward(archs, params, fw, X, eps, binary, weights, assoc_lambda, act, batc
         g["dec_bout"] = dl.sum(0)
         dg = dl @ q(p["dec_Wout"]).T
         for i in range(L - 1, -1, -1):
-            da = q(dg * dact(dpre[i], dacts[i + 1]))
+            d_i = dact(dpre[i], dacts[i + 1]) if masks is None else np.asarray(masks[m]["dec"][i], dtype=dg.dtype)
+            da = q(dg * d_i)
             g["dec_W%d" % (i + 1)] = dacts[i].T @ da
             g["dec_b%d" % (i + 1)] = da.sum(0)
             dg = da @ q(p["dec_W%d" % (i + 1)]).T
@@ -515,7 +522,8 @@ def backward(archs, params, fw, X, eps, binary, weights, assoc_lambda, act, batc
         g["enc_bsig"] = glv.sum(0)
         dh = gmu @ q(p["enc_Wmu"]).T + glv @ q(p["enc_Wsig"]).T
         for i in range(L - 1, -1, -1):
-            da = q(dh * dact(epre[i], eacts[i + 1]))
+            d_i = dact(epre[i], eacts[i + 1]) if masks is None else np.asarray(masks[m]["enc"][i], dtype=dh.dtype)
+            da = q(dh * d_i)
             g["enc_W%d" % (i + 1)] = eacts[i].T @ da
             g["enc_b%d" % (i + 1)] = da.sum(0)
             if i > 0:
@@ -624,7 +632,7 @@ class OracleAssocVAE(object):
     def _cast(self, X):
         return [np.asarray(x, dtype=self.dtype) for x in X]
 
-    def cost_and_grads(self, X, eps, batch_global=None):
+    def cost_and_grads(self, X, eps, batch_global=None, masks=None):
         X = self._cast(X)
         eps = self._eps(eps, X[0].shape[0])
         fw = forward(self.network_architectures, self.params, X, eps, self.binary, self.act, self.quant)
@@ -635,7 +643,7 @@ class OracleAssocVAE(object):
             cost = shard_cost(self.network_architectures, fw, X, self.binary, self.weights,
                               self.assoc_lambda, batch_global)
         grads, _ = backward(self.network_architectures, self.params, fw, X, eps, self.binary,
-                            self.weights, self.assoc_lambda, self.act, batch_global, self.quant)
+                            self.weights, self.assoc_lambda, self.act, batch_global, self.quant, masks)
         return cost, flatten_params(self.network_architectures, grads), fw
 
     def apply_gradients(self, gflat):

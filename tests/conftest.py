@@ -44,3 +44,31 @@ def golden():
         d["config"] = json.loads(str(d["config"]))
         out[name] = d
     return out
+
+
+def hip_relu_masks(model, archs):
+    """The relu decisions of the HIP path's LAST forward pass, in the shape oracle.backward(masks=...) takes: per modality
+    {"enc": [bool [B, width] per hidden layer], "dec": [...]} from the stored activations (avae_debug_fetch "E<m>_<k>" / "D<m>_<k>").
+    With them the oracle takes the same side of every relu kink as the kernels did, and a gradient comparison on the benchmark's
+    transfer function is a comparison of arithmetic, at the plain tolerance."""
+    import ctypes as C
+    B = model.batch_size
+    out = []
+    for m, na in enumerate(archs):
+        hs = na["n_hidden"] if na.get("n_hidden") else [na["n_hidden_recog_1"], na["n_hidden_recog_2"]]
+        d = {"enc": [], "dec": []}
+        for side, key in (("E", "enc"), ("D", "dec")):
+            for k, w in enumerate(hs):
+                buf = np.empty(B * int(w), dtype=np.float32)
+                cnt = C.c_size_t(0)
+                rc = model._L.avae_debug_fetch(model._h, ("%s%d_%d" % (side, m, k)).encode(), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(cnt))
+                assert rc == 0 and cnt.value == buf.size, model._L.avae_last_error(model._h)
+                d[key].append(buf.reshape(B, int(w)) > 0)
+        out.append(d)
+    return out
+
+
+def concat_masks(parts):
+    """row-wise concatenation of hip_relu_masks of several shards"""
+    return [{key: [np.concatenate([p[m][key][k] for p in parts]) for k in range(len(parts[0][m][key]))] for key in ("enc", "dec")}
+            for m in range(len(parts[0]))]

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, make_arch, synth_batch
+from conftest import GOLDEN, hip_relu_masks, make_arch, synth_batch
 from oracle import vae_assoc_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -242,7 +242,16 @@ def test_c4_full_size_gradients(V):
     assert abs(cost - float(G["cost_bf16"])) <= 5e-5 * abs(cost), (cost, float(G["cost_bf16"]))        # like-for-like oracle
     assert abs(cost - float(G["cost_f64"])) <= 1e-3 * abs(cost), (cost, float(G["cost_f64"]))           # north_star: 1e-3 of the fp64 run
     g = m.get_grads().astype(np.float64)
-    bad = _check_sampled(G, "bf16", g, "g", 3e-3, noise=0.5)
+    bad = _check_sampled(G, "bf16", g, "g", 3e-3, noise=0.5)        # the committed fixture: noise-aware (relu kink flips, see _check_sampled)
+    assert not bad, bad
+    # the plain 3e-3 bound on the BENCHMARK transfer function.  The oracle (rounding where the kernels round) is run
+    # here with the kernels' own relu decisions -- the stored activations of the pass above -- so no pre-activation within rounding
+    # of 0 can fall on different sides in the two runs, and EVERY entry of every tensor is compared, not a sample.
+    emu = O.OracleAssocVAE(c["archs"], c["binary"], c["act"], c["weights"], c["assoc_lambda"], c["lr"], c["B"],
+                           params_flat=p0.astype(np.float64), quant="bf16")
+    c_emu, g_emu, _ = emu.cost_and_grads(X, eps, masks=hip_relu_masks(m, c["archs"]))
+    assert abs(c_emu - float(G["cost_bf16"])) <= 1e-9 * abs(c_emu)
+    bad = [(n, e) for n, e in per_tensor_err(c["archs"], g, g_emu) if e > 3e-3]
     assert not bad, bad
     off = 0
     for t, (name, shp) in enumerate([(n, s) for na in c["archs"] for n, s in O.layer_shapes(na)]):

@@ -295,3 +295,36 @@ def test_oracle_reproduces_c4_fixture():
     cost, g, _fw = m.cost_and_grads(X, eps)
     assert abs(cost - float(G["cost_f64"])) <= 1e-10 * abs(cost)
     assert np.allclose(g[G["sample_idx"]], G["gsample_f64"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,tag,li", [("c3", "f64", None), ("c3", "bf16", None), ("c5", "f64_lam0", 0), ("c5", "f64_lam5", 5)])
+def test_oracle_reproduces_global_batch_fixtures(name, tag, li):
+    """Round 3: BASELINE C3 / C5 at their global batch of 2048 rows (tests/golden/make_golden_dp.py).  The fixture pins the oracle
+    against silent edits, and -- the data-parallel contract of SURVEY.md 8e -- the SUM over 8 shards of 256 rows, each computed with
+    batch_global = 2048, is the one-batch gradient and cost (vae_assoc.py:319-371 decides which terms carry 1/B)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_dp", os.path.join(GOLDEN, "make_golden_dp.py"))
+    dp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dp)
+    G = np.load(os.path.join(GOLDEN, name + "_b2048.npz"), allow_pickle=False)
+    c, X, eps, p0 = dp.inputs(name)
+    chk = [float(x.astype(np.float64).sum()) for x in X] + [float(eps.astype(np.float64).sum()), float(p0.astype(np.float64).sum())]
+    assert np.allclose(chk, G["checksum"], rtol=1e-12)
+    lam = c["assoc_lambda"] if li is None else dp.LAMBDAS[li]
+    quant = "bf16" if tag == "bf16" else None
+    m = O.OracleAssocVAE(c["archs"], c["binary"], c["act"], c["weights"], lam, c["lr"], c["B"], params_flat=p0.astype(np.float64), quant=quant)
+    cost, g, _ = m.cost_and_grads(X, eps[0])
+    assert abs(cost - float(G["cost_" + tag])) <= 1e-10 * abs(cost)
+    assert np.allclose(g[G["sample_idx"]], G["gsample_" + tag], rtol=1e-8, atol=1e-12)
+    if quant is None:               # shard sum (exact arithmetic: fp64 sums differ by rounding only)
+        gs, cs = np.zeros_like(g), 0.0
+        for r in range(8):
+            sh = O.OracleAssocVAE(c["archs"], c["binary"], c["act"], c["weights"], lam, c["lr"], 256, params_flat=p0.astype(np.float64))
+            cr, gr, _ = sh.cost_and_grads([x[256 * r:256 * (r + 1)] for x in X], eps[0][256 * r:256 * (r + 1)], batch_global=2048)
+            gs += gr
+            cs += cr
+        assert abs(cs - cost) <= 1e-10 * abs(cost)
+        assert np.abs(gs - g).max() <= 1e-10 * np.abs(g).max()
+    costs = [m.partial_fit(X, eps[s]) for s in range(dp.STEPS)]
+    assert np.allclose(costs, G["costs_" + tag], rtol=1e-10)
+    assert np.allclose(m.get_params()[G["sample_idx"]], G["p3sample_" + tag], rtol=1e-9, atol=1e-12)

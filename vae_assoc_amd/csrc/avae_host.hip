@@ -2922,6 +2922,27 @@ int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t m
 #ifdef AVAE_STAMPS
         else if (n == "stamps") { src = h->at<void>(h->off_stamps); cnt = (size_t)kStampLaunches * kStampBlocks * kStampWords * 2; }
 #endif
+        else if ((n[0] == 'E' || n[0] == 'D') && n.size() >= 4 && n.find('_') != std::string::npos) {
+            // "E<m>_<k>" / "D<m>_<k>": the stored output of encoder / decoder hidden layer k of modality m, dense [B][width] as fp32
+            // (tests: the relu decisions of the last forward pass)
+            const int m = std::atoi(n.c_str() + 1), k = std::atoi(n.c_str() + n.find('_') + 1);
+            if (m < 0 || m >= h->M || h->mods[m].conv || k < 0 || k >= h->mods[m].L) throw Err("debug_fetch: no such hidden layer");
+            const Act& a = n[0] == 'E' ? h->mods[m].E[k] : h->mods[m].D[k];
+            cnt = (size_t)h->B * a.width;
+            if (cnt > max_floats) throw Err("debug_fetch: destination too small");
+            HIP_OK(hipDeviceSynchronize());
+            std::vector<unsigned char> raw((size_t)h->B * a.ld * h->es);
+            HIP_OK(hipMemcpy(raw.data(), h->at<void>(a.rm), raw.size(), hipMemcpyDeviceToHost));
+            for (int r = 0; r < h->B; ++r)
+                for (int c = 0; c < a.width; ++c) {
+                    float v;
+                    if (h->es == 2) { const uint32_t u = (uint32_t)reinterpret_cast<const uint16_t*>(raw.data())[(size_t)r * a.ld + c] << 16; std::memcpy(&v, &u, 4); }
+                    else v = reinterpret_cast<const float*>(raw.data())[(size_t)r * a.ld + c];
+                    host_dst[(size_t)r * a.width + c] = v;
+                }
+            if (n_floats) *n_floats = cnt;
+            return;
+        }
         else if (n.rfind("mulv", 0) == 0 || n.rfind("g0_", 0) == 0) {
             const bool g0 = n[0] == 'g';
             const int m = std::atoi(n.c_str() + (g0 ? 3 : 4));
