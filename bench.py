@@ -175,6 +175,7 @@ def conv_launch_work(archs, B, es):
     overlap-add, split-K reductions, adjoint filter shadows, permutes, row sums) do no algorithmic work: their time counts
     against the step, their bytes are overhead."""
     out = {}
+    no_impl = bool(os.environ.get("AVAE_NO_IMPLICIT"))
 
     def add(name, by, fl):
         b0, f0 = out.get(name, (0, 0))
@@ -193,14 +194,18 @@ def conv_launch_work(archs, B, es):
             wts = k * k * ci * co + (0 if kind == "conv" else co)                                # convs carry no bias (vae_assoc.py:480-489)
             P += wts
             a_in, a_out = B * pin * ci, B * pout * co
-            fwd = {"enc1": "conv_enc1", "enc2": "conv_enc2", "enc3": "conv_enc3", "head": "fwd_head", "dec1": "conv_dec1",
-                   "dec2": "conv_dec2_scatter", "dec3": "conv_dec3_scatter", "dec4": "conv_dec4_direct", "out": "fwd_out_loss"}[name]
-            bwd = {"enc1": None, "enc2": "conv_bwd_enc2", "enc3": "conv_bwd_enc3", "head": "bwd_head", "dec1": "conv_dec1_latent",
-                   "dec2": "conv_bwd_dec2_adj", "dec3": "conv_bwd_dec3_adj", "dec4": "conv_bwd_dec4_direct", "out": "bwd_out"}[name]
+            # launch names of the implicit-GEMM plan (round 3), then of round 2's routes (AVAE_NO_IMPLICIT=1): a step has one or the other
+            fwd = {"enc1": ["conv_enc1"], "enc2": ["conv_enc2"], "enc3": ["conv_enc3"], "head": ["fwd_head"], "dec1": ["conv_dec1"],
+                   "dec2": ["conv_dec2", "conv_dec2_scatter"], "dec3": ["conv_dec3", "conv_dec3_scatter"], "dec4": ["conv_dec4_direct"], "out": ["fwd_out_loss"]}[name]
+            bwd = {"enc1": [], "enc2": ["conv_bwd_enc2"], "enc3": ["conv_bwd_enc3"], "head": ["bwd_head"], "dec1": ["bwd_dec1_latent", "conv_dec1_latent"],
+                   "dec2": ["conv_bwd_dec2", "conv_bwd_dec2_adj"], "dec3": ["conv_bwd_dec3", "conv_bwd_dec3_adj"], "dec4": ["conv_bwd_dec4_direct"], "out": ["bwd_out"]}[name]
             wgr = "conv_dec4_wgrad_direct" if name == "dec4" else "wgrad"
-            add(fwd, (a_in + wts + a_out) * es + (a_out * 4 if name in ("head", "out") else 0), 2 * B * macs)
-            if bwd:
-                add(bwd, (a_out + wts + 2 * a_in) * es, 2 * B * macs)
+            if no_impl:
+                fwd, bwd = fwd[-1:], bwd[-1:]
+            for nm in fwd[:1]:
+                add(nm, (a_in + wts + a_out) * es + (a_out * 4 if name in ("head", "out") else 0), 2 * B * macs)
+            for nm in bwd[:1]:
+                add(nm, (a_out + wts + 2 * a_in) * es, 2 * B * macs)
             add(wgr, (a_in + a_out) * es + wts * 4, 2 * B * macs)
         add("fwd_out_loss", B * (2 + 3) * int(na["n_z"]) * 4, 0)
         add("prep", B * int(na["n_input"]) * (4 + 4 + es), 0)

@@ -414,13 +414,42 @@ def test_conv_deconv_branch(V, dtype):
         assert np.abs(model.reconstruct(Xr, eps=e)[0] - emu.reconstruct(Xr, eps=e)[0]).max() <= tol
 
 
+@pytest.mark.parametrize("policy", [None, "E:fwb,H:fwb,D1:fwb,DT:fwb", "E:fw,H:fwb,D1:fwb,DT:wb"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_conv_branch_at_bench_size(V, dtype):
+def test_conv_branch_at_bench_size(V, monkeypatch, dtype, policy):
     """`bench.py --config c2conv` (depths 16/64, 64/16; batch 256): at this size the decoder's stages take the direct
-    (one output channel) and adjoint-frame routes with split reductions over 256 images x 49..784 pixels."""
+    (one output channel) and adjoint-frame routes with split reductions over 256 images x 49..784 pixels; the conv stages, the
+    heads and the first decoder stage are implicit GEMMs (default policy), or every stage is (the other two policies)."""
+    if policy:
+        monkeypatch.setenv("AVAE_IMPL_POLICY", policy)
     img = dict(make_arch("image", 784, 16, 64, 20), hidden_conv=True, n_hidden_gener_1=64, n_hidden_gener_2=16)
     jnt = make_arch("joint", 147, 200, 200, 20)
     check_step_parity(V, [img, jnt], [True, False], [50.0, 1.0], 8.0, "relu", 256, dtype, steps=1)
+
+
+def test_conv_plan_is_implicit_gemm(V, monkeypatch):
+    """with every product implicit (AVAE_IMPL_POLICY below) every conv / transposed-conv stage of the bench
+    configuration but the one-channel ends (the first conv reads a one-channel image: no 16-byte chunk of channels to stage; the last
+    transposed conv writes one: direct kernel) is an implicit GEMM -- no im2col, col2im, overlap-add or scatter launch is left in
+    the step, which has at most 24 launches (38 in round 2).  The DEFAULT policy keeps the transposed direction on round 2's routes,
+    where they do a quarter of the work (29 launches, faster: avae_host.hip::plan_memory); both are parity-tested below."""
+    import ctypes as C
+    monkeypatch.setenv("AVAE_IMPL_POLICY", "E:fwb,H:fwb,D1:fwb,DT:fwb")
+    img = dict(make_arch("image", 784, 16, 64, 20), hidden_conv=True, n_hidden_gener_1=64, n_hidden_gener_2=16)
+    jnt = make_arch("joint", 147, 200, 200, 20)
+    rng = np.random.default_rng(2)
+    X = synth_batch(rng, 256, [784, 147], [True, False])
+    m = V.AssocVariationalAutoEncoder([img, jnt], binary=[True, False], transfer_fct="relu", weights=[50, 1], assoc_lambda=8.0, batch_size=256,
+                                      compute_dtype="bf16", seed=1)
+    m._L.avae_timing_enable(m._h, 1)
+    m.partial_fit(X, return_cost=False)
+    buf = C.create_string_buffer(1 << 16)
+    m._L.avae_timing_report(m._h, buf, len(buf))
+    m._L.avae_timing_enable(m._h, 0)
+    names = [ln.split()[0] for ln in buf.value.decode().splitlines() if not ln.startswith("_null")]
+    helpers = [n for n in names if any(k in n for k in ("col2im", "overlap", "scatter", "rowsum")) or (n.endswith("_im2col") and n != "conv_enc1_im2col")]
+    assert not helpers, helpers
+    assert len(names) <= 24, (len(names), names)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -524,7 +553,12 @@ def test_tail_product_route(V, monkeypatch, dtype, B):
     assert "bwd_dec1_latent+bwd_head" in names, names      # ([dmu | dlv] = 40 columns: one 128-byte K tile of bf16, two of fp32)
 
 
-@pytest.mark.parametrize("env", [{"AVAE_NO_THIN": "1"}, {"AVAE_NO_ADJ": "1"}, {"AVAE_NO_THIN": "1", "AVAE_NO_ADJ": "1"}, {"AVAE_NO_SINK": "1"}, {"AVAE_NO_SUMS_MERGE": "1"}, {"AVAE_NO_WADJ_FOLD": "1"}])
+@pytest.mark.parametrize("env", [{"AVAE_NO_THIN": "1"}, {"AVAE_NO_ADJ": "1"}, {"AVAE_NO_THIN": "1", "AVAE_NO_ADJ": "1"}, {"AVAE_NO_SINK": "1"}, {"AVAE_NO_SUMS_MERGE": "1"}, {"AVAE_NO_WADJ_FOLD": "1"},
+                                 {"AVAE_NO_IMPLICIT": "1"}, {"AVAE_NO_IMPLICIT": "1", "AVAE_NO_THIN": "1"}, {"AVAE_NO_IMPLICIT": "1", "AVAE_NO_ADJ": "1"},
+                                 {"AVAE_NO_IMPLICIT": "1", "AVAE_NO_WADJ_FOLD": "1"}, {"AVAE_NO_IMPLICIT": "1", "AVAE_NO_SUMS_MERGE": "1"},
+                                 {"AVAE_IMPL_POLICY": "E:fwb,H:fwb,D1:fwb,DT:fwb"}, {"AVAE_IMPL_POLICY": "E:fw,H:fwb,D1:fwb,DT:b"},
+                                 {"AVAE_IMPL_POLICY": "E:fw,H:fwb,D1:fwb,DT:wb"}, {"AVAE_IMPL_POLICY": "E:b,H:b,D1:b,DT:w"},
+                                 {"AVAE_IMPL_POLICY": "E:fwb,H:fwb,D1:fwb,DT:fwb", "AVAE_NO_THIN": "1"}])
 def test_planner_switches_conv_routes(V, monkeypatch, env):
     """Conv stages through the patch-matrix route instead of the direct / adjoint-frame ones; the MLP modality's hidden layers as
     launches of their own instead of riding in the conv modality's GEMM launches (AVAE_NO_SINK); the sums behind the weight

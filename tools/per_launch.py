@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-launch durations of the train step from a rocprofv3 --kernel-trace CSV.
 
-  python tools/per_launch.py <kernel_trace.csv> <names.json|bench-json-line> > profiles/rNN_<cfg>_per_launch.json
+  python tools/per_launch.py <kernel_trace.csv> <names.json|bench-json-line> [<log of the profiled bench run>] > profiles/rNN_<cfg>_per_launch.json
 
 k_grouped runs every GEMM launch of the step, so rocprofv3's per-kernel-name statistics lump them
 together.  A graph replay issues the launches in a fixed order (fwd_*, bwd_*, wgrad*, adam), so the n-th
@@ -53,8 +53,18 @@ def main():
     prep = {"calls": len(pd), "avg_us": round(sum(pd) / len(pd), 2), "min_us": round(min(pd), 2),
             "workgroups": max(wgs(r) for r in preps), "steps_per_call": round(len(steps) / len(pd), 1),
             "avg_us_per_step": round(sum(pd) / len(steps), 2)}
-    print(json.dumps({"source": "rocprofv3 --kernel-trace, %d graph-replayed steps" % len(steps), "prep": prep,
-                      "launches": out, "sum_avg_us": round(sum(v["avg_us"] for v in out.values()) + prep["avg_us_per_step"], 2)}, indent=1))
+    res = {"source": "rocprofv3 --kernel-trace, %d graph-replayed steps" % len(steps), "prep": prep,
+           "launches": out, "sum_avg_us": round(sum(v["avg_us"] for v in out.values()) + prep["avg_us_per_step"], 2)}
+    # The profiler slows the run down (and DVFS differs): say by how much, so that nobody reads the sum as the step time.
+    res["unprofiled_ms_per_step"] = oj.get("ms_per_step")
+    if len(sys.argv) > 3:
+        for line in open(sys.argv[3]):
+            if line.startswith("{") and '"ms_per_step"' in line:
+                res["profiled_run_ms_per_step"] = json.loads(line)["ms_per_step"]
+    res["note"] = ("kernel durations under rocprofv3 (dispatch begin -> end); the profiled run is slower than the unprofiled one "
+                   "(profiled_run_ms_per_step vs unprofiled_ms_per_step) and the inter-kernel gaps are not in sum_avg_us: "
+                   "these averages rank the launches, they do not decompose the unprofiled step")
+    print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":

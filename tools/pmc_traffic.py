@@ -1,70 +1,66 @@
 #!/usr/bin/env python3
 """Per-launch HBM traffic from the two rocprofv3 --pmc passes of tools/pmc_traffic.sh.
 
-Launches of one step are told apart by their position between two k_prep dispatches (every GEMM
-launch runs the same kernel, k_grouped).  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the
-counters are in KiB and gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes
-(MI355X_MICROARCH.md, "HBM").  Writes profiles-ready JSON to <out>/traffic.json."""
+  python tools/pmc_traffic.py <out dir> <config> <bench JSON of the same config (its "launch_order")>
+
+Launches of one step are told apart by their position between two k_prep dispatches: the profiled run submits every step on its
+own (--single-step), so the n-th dispatch after a k_prep is the n-th launch of bench's `launch_order` (any config: MLP, C4, conv
+branch).  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in KiB and gfx950's FETCH_SIZE tallies 128-byte
+requests at 64 bytes (MI355X_MICROARCH.md, "HBM").  Writes profiles-ready JSON to <out>/traffic.json, with bench's algorithmic
+bytes per launch beside the counters."""
 import collections
 import csv
 import glob
 import json
 import sys
 
-out, cfg = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "c2")
+out, cfg, order_file = sys.argv[1], sys.argv[2], sys.argv[3]
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import bench  # noqa: E402
 
 archs, B, dtype, label = bench.CONFIGS[cfg]
+names = json.loads(open(order_file).read().strip().splitlines()[-1])["launch_order"]
 
 
 def per_position(counter, sub):
     f = glob.glob("%s/%s/**/*counter_collection.csv" % (out, sub), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    seq, pos, steps = collections.defaultdict(list), -1, 0
+    steps, cur = [], None
     for r in rows:
         n = r["Kernel_Name"]
         if "k_prep" in n:
-            pos, steps = 0, steps + 1
-            if steps > 12:                      # skip warm-up
-                seq["prep"].append(float(r["Counter_Value"]))
-            continue
-        if pos < 0:
-            continue
-        if "k_grouped" in n or "k_small" in n or "k_adam" in n:
-            pos += 1
-            if steps > 12:
-                seq[pos].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in seq.items() if v}
+            if cur is not None:
+                steps.append(cur)
+            cur = [("prep", float(r["Counter_Value"]))]
+        elif cur is not None and "avae" in n:               # every kernel of the library lives in namespace avae
+            cur.append((None, float(r["Counter_Value"])))
+    steps = [s for s in steps[12:] if len(s) == len(names) + 1]          # skip warm-up; whole steps only
+    seq = collections.defaultdict(list)
+    for s in steps:
+        for pos, (_, v) in enumerate(s):
+            seq[pos].append(v)
+    return {k: sum(v) / len(v) for k, v in seq.items()}, len(steps)
 
 
-fetch = per_position("FETCH_SIZE", "fetch")
-write = per_position("WRITE_SIZE", "write")
-L = len(archs[0]["n_hidden"])
-cd = lambda a, b: -(-a // b)
-latent_alone = (sum(cd(B, 256) * cd(na["n_input"], 64) for na in archs) >= 192 and sum(cd(B, 128) * cd(na["n_input"], 128) for na in archs) >= 192)
-import os
-# small nets: fwd_dec1 and bwd_head ride in the launch that produces their input (avae_host.hip::fuse_tail; AVAE_NO_TAIL=1 keeps them apart)
-tail = not latent_alone and not os.environ.get("AVAE_NO_TAIL")
-names = (["fwd_enc%d" % (k + 1) for k in range(L)] + (["fwd_head+fwd_dec1"] if tail else ["fwd_head"]) + (["latent"] if latent_alone else [])
-         + ["fwd_dec%d" % (k + 1) for k in range(1 if tail else 0, L)] + ["fwd_out_loss", "bwd_out"]
-         + ["bwd_dec%d" % (k + 1) for k in range(L - 1, 0, -1)] + (["bwd_dec1_latent+bwd_head"] if tail else ["bwd_dec1_latent", "bwd_head"])
-         + ["bwd_enc%d" % (k + 1) for k in range(L - 1, 0, -1)])
-fused_adam = tail and not os.environ.get("AVAE_NO_ADAM_FUSE") and not os.environ.get("AVAE_NO_LEAN")      # small nets: "wgrad+adam" is ONE launch
-if fused_adam:
-    names += ["wgrad+adam"]
-else:
-    n_wg = len([k for k in fetch if k != "prep"]) - len(names) - 1            # the step ends with k_adam
-    names += (["wgrad"] if n_wg == 1 else ["wgrad%d" % (i + 1) for i in range(n_wg)]) + ["adam"]
-res = {"config": label, "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, mean over steps; rocprofv3 --pmc, separate passes",
+fetch, nf = per_position("FETCH_SIZE", "fetch")
+write, nw = per_position("WRITE_SIZE", "write")
+work, P = bench.launch_work(archs, B, 2 if dtype == "bf16" else 4)
+res = {"config": label, "steps_averaged": [nf, nw],
+       "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, mean over steps; rocprofv3 --pmc, separate passes; "
+               "algorithmic_bytes = bench.launch_work (a fused a+b launch: the sum of its parts, minus the gradient re-read for wgrad+adam)",
        "launches": {}}
-for key in ["prep"] + list(range(1, len(names) + 1)):
-    name = key if key == "prep" else names[key - 1]
-    f, w = fetch.get(key, 0.0), write.get(key, 0.0)
-    res["launches"][name] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "hbm_bytes": int((2 * f + w) * 1024)}
+for pos, name in enumerate(["prep"] + names):
+    f, w = fetch.get(pos, 0.0), write.get(pos, 0.0)
+    parts = name.split("+")
+    alg = sum(work[p][0] for p in parts) if all(p in work for p in parts) else None
+    if alg is not None and parts == ["wgrad", "adam"]:
+        alg -= 4 * P
+    res["launches"][name] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "hbm_bytes": int((2 * f + w) * 1024), "algorithmic_bytes": alg}
 json.dump(res, open(out + "/traffic.json", "w"), indent=1)
 tot = sum(v["hbm_bytes"] for v in res["launches"].values())
+alg = sum(v["algorithmic_bytes"] or 0 for v in res["launches"].values())
 for k, v in res["launches"].items():
-    print("%-16s fetch %9.1f KiB  write %9.1f KiB  hbm %8.2f MB" % (k, v["FETCH_SIZE_KiB"], v["WRITE_SIZE_KiB"], v["hbm_bytes"] / 1e6))
-print("step total %.2f MB" % (tot / 1e6))
+    print("%-28s fetch %9.1f KiB  write %9.1f KiB  hbm %8.2f MB  algorithmic %s" % (k, v["FETCH_SIZE_KiB"], v["WRITE_SIZE_KiB"], v["hbm_bytes"] / 1e6,
+                                                                                 "%.2f MB" % (v["algorithmic_bytes"] / 1e6) if v["algorithmic_bytes"] else "-"))
+print("step total %.2f MB moved, %.2f MB algorithmic" % (tot / 1e6, alg / 1e6))

@@ -11,6 +11,7 @@ OUT=${2:-/root/repo/gpurun_out/pmc_traffic_$CFG}
 STEPS=${3:-40}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 /root/repo/bench.py --config $CFG --steps $STEPS --warmup 10 --kernel-steps 0 --no-cpu-baseline --no-extras --single-step > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 /root/repo/bench.py --config $CFG --steps $STEPS --warmup 10 --kernel-steps 0 --no-cpu-baseline --no-extras --single-step > $OUT/write.log 2>&1
-python3 /root/repo/tools/pmc_traffic.py $OUT $CFG
+python3 /root/repo/bench.py --config $CFG --steps 32 --warmup 8 --repeats 1 --kernel-steps 4 --no-cpu-baseline --no-extras > $OUT/order.json 2> $OUT/order.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 /root/repo/bench.py --config $CFG --steps $STEPS --warmup 10 --repeats 1 --kernel-steps 0 --no-cpu-baseline --no-extras --single-step > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 /root/repo/bench.py --config $CFG --steps $STEPS --warmup 10 --repeats 1 --kernel-steps 0 --no-cpu-baseline --no-extras --single-step > $OUT/write.log 2>&1
+python3 /root/repo/tools/pmc_traffic.py $OUT $CFG $OUT/order.json

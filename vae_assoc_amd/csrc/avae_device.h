@@ -89,6 +89,7 @@ struct WorkItem {
     int tail_ldw, tail_ldo, tail_ldx;
     int tail_act;
     int tail_kt;             // K tiles of the consuming layer's product: 1, or 2 (fp32 [dmu | dlv] with n_z > 16)
+    int conv;                // > 0: the A operand is an implicit patch matrix, descriptor conv - 1 of the launch's ConvA table (below)
     // K_LATENT reuses the pointer fields: [mu|lv] inputs of modality 0..3 = A, B, aux0, aux1;
     // static-gradient outputs g0 of modality 0..3 = out0, out1, out2, aux2.
     // K_COST: scale = lr, lambda = beta1, inv_bg = beta2 (it also publishes this step's Adam lr_t).
@@ -97,6 +98,26 @@ struct WorkItem {
 // One launch = up to kMaxItemsPerLaunch work items, passed BY VALUE in the kernel-argument
 // segment together with the first block index of every item: a workgroup finds and reads its item
 // without a chain of dependent loads from HBM, and no device-side table has to be kept in sync.
+// Implicit-GEMM conv / transposed conv (reference vae_assoc.py:169-199,249-278, deconv.py:107): the patch matrix
+//   P[(b,oh,ow)][(kh,kw,ci)] = X[b, (oh*so + kh - pad)/d, (ow*so + kw - pad)/d, ci]   (0 where not divisible / out of range)
+// is never stored: a GEMM whose A operand is P computes the address of every 16-byte chunk it stages -- Cin*elem_size is a multiple
+// of 16, so a chunk is 8 (bf16) / 4 (fp32) channels of ONE tap of one source pixel; an invalid tap reads a 16-byte block of
+// zeros; the chunk at column K = k*k*Cin reads {1, 0, ...} when `ones` (the bias column of a stored patch matrix), zeros beyond.
+// The LDS-DMA takes a per-lane source address, so the staged image is byte for byte the one a stored P would give.
+// One geometry covers conv (so = stride, d = 1), transposed conv in gather form (so = 1, d = stride, pad = k-1-pad_before, the
+// filter flipped in the matrix), flatten + dense (k = map size, VALID) and, with so <-> d swapped on the stage's OUTPUT gradient,
+// every input gradient (adjoint form).  Divisions are multiplications by magic numbers (mg_x = floor(2^32 / x) + 1).
+struct ConvA {
+    const void* src;         // source map, compute dtype: element (b, pixel, c) at b*src_sb + pixel*src_sp + c
+    const void* consts;      // [16 B of zeros][16 B {1, 0, ...} in the compute dtype]
+    int M, K;                // rows B*OH*OW (rows beyond read zeros), k*k*Cin
+    int OHW, OW, IH, IW, Cin;
+    int k, so, d, pad;
+    int src_sb, src_sp;
+    int ones;
+    unsigned mg_ohw, mg_ow, mg_k, mg_cin;
+};
+constexpr int kMaxConvA = 12;
 constexpr int kMaxItemsPerLaunch = 12;
 constexpr int kMaxPf = 4;
 // Grid: x = tile slot inside an item (a multiple of 8, at least the largest item's tile count), y = item.
@@ -109,6 +130,7 @@ struct LaunchArgs {
     int n_pf;                // 8-wave NT tiles: weight panels of the NEXT launch to pull into the Infinity Cache (0..kMaxPf)
     const void* pf_ptr[4];   // ... their first bytes
     int pf_lines[4];         // ... and sizes in 128-byte lines
+    const ConvA* conv_tab;   // device table of the launch's implicit patch matrices (WorkItem::conv indexes it; null: none)
     WorkItem items[kMaxItemsPerLaunch];
 };
 
@@ -125,7 +147,8 @@ struct TnItem {
     int ksplit, kchunk;
     int bias_row;            // see WorkItem::bias_row
     int tile_off, tile_cnt;  // this entry covers tiles [tile_off, tile_off + tile_cnt) of the item's tile list: the host cuts
-    int pad;                 // items with many tiles into several entries so that the grid (x = longest entry) is not mostly padding
+    int conv;                // items with many tiles into several entries so that the grid (x = longest entry) is not mostly padding.
+                             // conv > 0: A (the K-major operand X) is the implicit patch matrix conv - 1 of TnLaunchArgs::conv_tab
     // k_small_tn with the optimiser in its epilogue (TnLaunchArgs::adam): the layer's two compute-dtype shadows
     void* W; void* Wt;       // [M][ldw] (dgrad operand), [N][ldt] (forward operand)
     int ldw, ldt;
@@ -144,6 +167,7 @@ struct TnLaunchArgs {
     long long d_theta, d_m, d_v;
     float beta1, beta2, eps;
     const DevState* st;      // lr_t of this step (published by the K_COST item earlier in the step)
+    const ConvA* conv_tab;
     TnItem items[kMaxTnItems];
 };
 
@@ -280,6 +304,7 @@ struct ThinSeg {
     float* part;             // mode 2: [blocks][Kp]
     int Kp;                  // roundup(k*k*Cin + 1, 4)
     int block_base;
+    int img_y, img_dy;       // > 0: elements from one image's map to the next in Y / dY (dense rows); 0: OH*OW*ldy / OH*OW*lddy
 };
 struct ThinArgs { ThinSeg seg[kMaxMod]; int n_seg; int mode; };
 void launch_thin(int compute_dtype, const ThinArgs& a, int n_blocks, hipStream_t s);

@@ -114,6 +114,14 @@ struct ConvStage {
     size_t apart = 0;
     size_t rs_part = 0;    // bias gradient: partial column sums of dY [kRowsumBlocks][rs_cols4]
     int rs_cols4 = 0;
+    // Implicit-GEMM routes of the training plan (ConvA, avae_device.h): the stage's patch matrix is never stored.
+    bool impl = false;     // forward + filter gradient: A = implicit P of the stage's input (needs Cin * elem_size % 16 == 0)
+    bool impl_w = false;   // filter gradient: dW = P^T . dY with P implicit (gather form on the stage's input); impl implies it (no stored P then)
+    bool impl_bwd = false; // input gradient: A = implicit patch matrix of the stage's OUTPUT gradient with the adjoint geometry, B = Wadj
+                           // (needs Cout * elem_size % 16 == 0 and an input that has a gradient)
+    int cin_real = 0;      // channels of the stage's input in the flat parameter layout (the first decoder stage pads n_z up to a whole chunk)
+    bool dense_map = false;// the direct one-channel 28x28 stage: its output / output gradient are stored as dense rows [B][784 (+1)],
+                           // which makes the dense output layer behind it an ordinary dense layer (no flatten gather, no col2im)
     bool thin = false;     // one output channel: direct kernels (k_thin) instead of im2col -> GEMM -> col2im in the training plan
     size_t thin_part = 0;  // its filter-gradient partial sums [thin_blocks][Kp]
     int thin_blocks = 0, thin_kp = 0;
@@ -227,6 +235,8 @@ struct avae_handle {
                    ServeInArgs in_lean; int in_lean_grid = 0; bool lean_in = false; };
     std::vector<Serve> serve;
     size_t off_slot = 0;
+    size_t off_consts = 0, off_conv_tab = 0;   // 32 B {zeros | one, 0...}; device copy of conv_tab
+    std::vector<ConvA> conv_tab;             // implicit patch matrices of the training plan
 
     hipGraphExec_t g_full = nullptr, g_eval = nullptr;
     hipGraphExec_t g_multi[2] = {nullptr, nullptr};   // kMultiSizes[i] whole steps per replay (avae_train_steps)
@@ -371,8 +381,14 @@ void plan_memory(avae_handle* h) {
             md.Z = act_B(nz, false);
             md.dH = act_B(2 * nz, false);
             md.dO = act_B(md.n_in, false);
-            auto stage = [&](int IH, int Cin, int OH, int Cout, int k, int so, int d, int pad, bool bias, int act, int flat, bool plain_out) {
+            const bool no_impl = std::getenv("AVAE_NO_IMPLICIT") != nullptr;
+            auto stage = [&](int IH, int Cin_in, int OH, int Cout, int k, int so, int d, int pad, bool bias, int act, int flat, bool plain_out, bool has_dgrad) {
                 ConvStage st;
+                // whole 16-byte chunks of channels per tap where that takes a few zero channels (the first decoder stage reads z: n_z
+                // channels, padded here; the pad channels' filter rows stay zero and are not part of the flat parameters)
+                const int cpc = 16 / es;
+                const int Cin = (IH == 1 && flat == 1 && !no_impl) ? (int)rup(Cin_in, cpc) : Cin_in;
+                st.cin_real = Cin_in;
                 st.g = ConvGeom{B, IH, IH, Cin, OH, OH, k, so, d, pad, 0, 0, bias ? 1 : 0};
                 st.bias = bias; st.act = act; st.flat = flat;
                 const int K = k * k * Cin, rows = B * OH * OH;
@@ -380,13 +396,50 @@ void plan_memory(avae_handle* h) {
                 st.P = make_act(b, K, bias, rows, KU, es);
                 const bool thin = Cout == 1 && plain_out && flat == 1 && IH > 1 && IH * IH * Cin <= kThinIn && OH * OH <= kThinOut && K + 1 <= kThinF &&
                                   !std::getenv("AVAE_NO_THIN");
+                // (the dense layer behind the flattened 28x28 map, flat == 2, is never a conv: it reads the map as stored -- dense_map -- or its flatten gather)
+                // (row -> (image, pixel) by magic-number division: exact while rows x pixels-per-image < 2^32)
+                const bool fits = (uint64_t)rows * (uint64_t)(OH * OH) < (1ull << 32) && (uint64_t)B * IH * IH * (uint64_t)(IH * IH) < (1ull << 32);
+                {   // Which products of which stage run as implicit GEMMs.  The gather is dense in the conv direction (big map -> small
+                    // map: every tap of every row is a real pixel) and mostly zeros in the transposed direction (zero insertion / full
+                    // padding: 3 of 4 taps of a stride-2 transposed conv read the zero block), where the scatter product on the small
+                    // side (round 2's adjoint-frame route) or the explicit patch gradients do a quarter of the work.  Measured on c2conv
+                    // (tools/conv_policy_ab.sh, one box, ms per step): everything explicit 0.2715; everything implicit 0.2696 (22
+                    // launches: conv forward 7.3 us vs 8.2 + 4.4, heads 7.5 vs 4.2 + 5.3, first decoder stage 4.2 vs 4.3 + 4.4, its
+                    // latent dgrad 6.8 vs 4.5 + 6.0 -- but transposed-conv forward 24.3 vs 11.7 + 7.2, conv dgrad 23.6 vs 10.4 + 6.6,
+                    // gather-form filter gradients 43 vs 17); implicit where the gather is dense 0.2376 (29 launches) = the default:
+                    //   E  conv stages        forward + filter gradient implicit, input gradient by patch gradients + col2im
+                    //   H  heads, D1 first decoder stage (1x1 input)   everything implicit
+                    //   DT transposed convs   round 2's adjoint-frame route (scatter product + overlap-add, Padj for both gradients);
+                    //                         their implicit input gradient alone ("DT:b": 8.3 us vs 5.9 with Padj at hand) 0.2436
+                    // Letters f / w / b = forward / filter gradient / input gradient; AVAE_IMPL_POLICY overrides (A/B runs, tests).
+                    const char* pol = std::getenv("AVAE_IMPL_POLICY");
+                    const std::string policy = pol ? pol : "E:fw,H:fwb,D1:fwb,DT:";
+                    const std::string cls = flat == 0 ? "E" : flat == 3 ? "H" : (flat == 1 && IH == 1) ? "D1" : flat == 1 ? "DT" : "X";
+                    std::string letters;
+                    for (size_t pos = 0; pos < policy.size();) {
+                        const size_t e = policy.find(',', pos), c = policy.find(':', pos);
+                        const size_t end = e == std::string::npos ? policy.size() : e;
+                        if (c != std::string::npos && c < end && policy.substr(pos, c - pos) == cls) letters = policy.substr(c + 1, end - c - 1);
+                        pos = end + 1;
+                    }
+                    const bool geo = !no_impl && fits && !thin && flat != 2 && (so == 1 || so == 2) && (d == 1 || d == 2);
+                    st.impl = geo && letters.find('f') != std::string::npos && (Cin * es) % 16 == 0;
+                    st.impl_w = geo && (st.impl || letters.find('w') != std::string::npos) && (Cin * es) % 16 == 0;
+                    st.impl_bwd = geo && letters.find('b') != std::string::npos && has_dgrad && (Cout * es) % 16 == 0;
+                }
                 if (plain_out) {     // hidden conv stage: own output / gradient buffers
-                    // (the direct stage's one-channel maps are read and written pixel by pixel, never as a GEMM operand: 8
-                    // elements per pixel instead of a K-padded row of 64 keep them 8x smaller -- 3 MB instead of 26 MB)
-                    // -- only for the LAST map (28x28), whose consumer is the flatten gather; an earlier one-channel stage feeds a GEMM
-                    const int compact = thin && OH == 28 ? 8 : 0;
-                    st.Y = make_act(b, Cout, false, rows, KU, es, compact);
-                    st.dY = make_act(b, Cout, false, rows, KU, es, compact);
+                    // (the direct stage's one-channel maps are read and written pixel by pixel: the LAST map (28x28), whose consumer
+                    // is the dense output layer, is stored as dense rows [B][784 | 1]: that layer then reads it as any dense layer
+                    // reads its input.  AVAE_NO_IMPLICIT keeps round 2's compact 8-elements-per-pixel layout + flatten gather.)
+                    st.dense_map = thin && OH == 28 && !no_impl;
+                    if (st.dense_map) {
+                        st.Y = make_act(b, OH * OH, true, B, KU, es);
+                        st.dY = make_act(b, OH * OH, false, B, KU, es);
+                    } else {
+                        const int compact = thin && OH == 28 ? 8 : 0;
+                        st.Y = make_act(b, Cout, false, rows, KU, es, compact);
+                        st.dY = make_act(b, Cout, false, rows, KU, es, compact);
+                    }
                 }
                 st.lddp = (int)rup(K, 8);
                 st.dP = b.take((size_t)rows * st.lddp * 4);
@@ -403,7 +456,7 @@ void plan_memory(avae_handle* h) {
                 // transposed convs that upsample (d > 1) or pad heavily have an OUTPUT far larger than their input: the fp32 patch
                 // gradients [B*OH*OW][k*k*Cin] of the plain path (160 MB for 7x7x32 -> 14x14x16) are replaced by the compute-type
                 // patch matrix of the output gradient, [B*IH*IW][k*k*Cout] (11 MB), times the adjoint filter
-                if (flat == 1 && plain_out && !thin && IH > 1 && Cout <= 64 && (long)IH * IH * Cout < (long)OH * OH * Cin * 2 && !std::getenv("AVAE_NO_ADJ")) {
+                if (flat == 1 && plain_out && !thin && !st.impl && IH > 1 && Cout <= 64 && (long)IH * IH * Cout < (long)OH * OH * Cin * 2 && !std::getenv("AVAE_NO_ADJ")) {
                     st.adj = true;
                     st.Padj = make_act(b, k * k * Cout, false, B * IH * IH, KU, es);
                     st.ldadj = (int)rup(k * k * Cout, KU);
@@ -427,33 +480,41 @@ void plan_memory(avae_handle* h) {
                     st.rs_cols4 = (int)rup(Cout, 4);
                     st.rs_part = b.take((size_t)kRowsumBlocks * st.rs_cols4 * 4);
                 }
+                if (st.impl_bwd && !st.Wadj) {      // adjoint filter shadow [Cin][(kh', kw', co)]: the B operand of the implicit input gradient
+                    st.ldadj = (int)rup(k * k * Cout, KU);
+                    st.Wadj = b.take(rup(Cin, kRowAlign) * (size_t)st.ldadj * es);
+                }
                 if (thin) {
                     st.thin = true;
                     st.thin_kp = (int)rup(K + 1, 4);
                     st.thin_blocks = B * kThinSplit;      // filter-gradient partial sums: one slice per workgroup
                     st.thin_part = b.take((size_t)st.thin_blocks * st.thin_kp * 4);
                 }
-                pflat += (size_t)K * Cout + (flat == 0 ? 0 : Cout);
+                pflat += (size_t)k * k * Cin_in * Cout + (flat == 0 ? 0 : Cout);
                 return st;
             };
             // encoder: conv k5 s2 SAME (pad-before 1), conv k5 s2 SAME, conv k5 s1 VALID, flatten(3x3) + dense heads
-            md.cenc.push_back(stage(28, 1, 14, R1, 5, 2, 1, 1, false, AVAE_ACT_IDENTITY, 0, true));
-            md.cenc.push_back(stage(14, R1, 7, 2 * R1, 5, 2, 1, 1, false, AVAE_ACT_IDENTITY, 0, true));
-            md.cenc.push_back(stage(7, 2 * R1, 3, R2, 5, 1, 1, 0, false, AVAE_ACT_IDENTITY, 0, true));
-            md.cenc.push_back(stage(3, R2, 1, 2 * nz, 3, 1, 1, 0, true, AVAE_ACT_IDENTITY, 3, false));
+            md.cenc.push_back(stage(28, 1, 14, R1, 5, 2, 1, 1, false, AVAE_ACT_IDENTITY, 0, true, false));
+            md.cenc.push_back(stage(14, R1, 7, 2 * R1, 5, 2, 1, 1, false, AVAE_ACT_IDENTITY, 0, true, true));
+            md.cenc.push_back(stage(7, 2 * R1, 3, R2, 5, 1, 1, 0, false, AVAE_ACT_IDENTITY, 0, true, true));
+            md.cenc.push_back(stage(3, R2, 1, 2 * nz, 3, 1, 1, 0, true, AVAE_ACT_IDENTITY, 3, false, true));
             // decoder: transposed convs as convs of the dilated input with the flipped filter (pad = k-1-pad_before)
-            md.cdec.push_back(stage(1, nz, 3, G1, 3, 1, 1, 2, true, AVAE_ACT_SIGMOID, 1, true));
-            md.cdec.push_back(stage(3, G1, 7, G1 / 2, 5, 1, 1, 4, true, AVAE_ACT_SIGMOID, 1, true));
-            md.cdec.push_back(stage(7, G1 / 2, 14, G2, 5, 1, 2, 3, true, AVAE_ACT_SIGMOID, 1, true));
-            md.cdec.push_back(stage(14, G2, 28, 1, 5, 1, 2, 3, true, AVAE_ACT_SIGMOID, 1, true));
-            md.cdec.push_back(stage(28, 1, 1, md.n_in, 28, 1, 1, 0, true, AVAE_ACT_IDENTITY, 2, false));
+            md.cdec.push_back(stage(1, nz, 3, G1, 3, 1, 1, 2, true, AVAE_ACT_SIGMOID, 1, true, true));
+            md.cdec.push_back(stage(3, G1, 7, G1 / 2, 5, 1, 1, 4, true, AVAE_ACT_SIGMOID, 1, true, true));
+            md.cdec.push_back(stage(7, G1 / 2, 14, G2, 5, 1, 2, 3, true, AVAE_ACT_SIGMOID, 1, true, true));
+            md.cdec.push_back(stage(14, G2, 28, 1, 5, 1, 2, 3, true, AVAE_ACT_SIGMOID, 1, true, true));
+            md.cdec.push_back(stage(28, 1, 1, md.n_in, 28, 1, 1, 0, true, AVAE_ACT_IDENTITY, 2, false, true));
             md.head = md.cenc[3].d;
             md.outl = md.cdec[4].d;
             auto src = [](ConvStage& st, int sb, int sp) { st.g.src_sb = sb; st.g.src_sp = sp; };
             src(md.cenc[0], md.X0.ld, 1);
             for (int i = 1; i < 4; ++i) { const ConvStage& pv = md.cenc[i - 1]; src(md.cenc[i], pv.g.OH * pv.g.OW * pv.Y.ld, pv.Y.ld); }
             src(md.cdec[0], md.Z.ld, 0);
-            for (int i = 1; i < 5; ++i) { const ConvStage& pv = md.cdec[i - 1]; src(md.cdec[i], pv.g.OH * pv.g.OW * pv.Y.ld, pv.Y.ld); }
+            for (int i = 1; i < 5; ++i) {
+                const ConvStage& pv = md.cdec[i - 1];
+                if (pv.dense_map) src(md.cdec[i], pv.Y.ld, 1);        // one channel, dense rows: image stride = row stride, pixel stride 1
+                else src(md.cdec[i], pv.g.OH * pv.g.OW * pv.Y.ld, pv.Y.ld);
+            }
         }
         md.ld32 = (int)rup(md.n_in, 8);      // multiple of the widest epilogue vector (8 elements)
         md.X32 = stage_x32[m];
@@ -503,6 +564,8 @@ void plan_memory(avae_handle* h) {
     h->off_adam = b.take(n_adam * sizeof(AdamItem));
     h->off_adam_b = b.take(n_adam * sizeof(AdamItem));
     h->off_slot = b.take(sizeof(ServeSlot));
+    h->off_consts = b.take(32);
+    h->off_conv_tab = b.take(4 * kMaxConvA * kMaxMod * sizeof(ConvA));
     h->off_inf = b.off;
     for (int m = 0; m < h->M; ++m) b.take(2 * ((size_t)h->mods[m].L + 1) * sizeof(WorkItem));
 #ifdef AVAE_STAMPS
@@ -538,7 +601,8 @@ void convert_params(const avae_handle* h, float* flat, float* internal) {
         if (st.flat == 0) {            // tf.nn.conv2d filter [k,k,ci,co] == matrix rows (kh,kw,ci) x cols co; no bias
             for (int r = 0; r < K; ++r) for (int c = 0; c < Co; ++c) xfer(I[(size_t)r * d.ld + c]);
         } else if (st.flat == 1) {     // conv2d_transpose filter [k,k,co,ci] (deconv.py:78), flipped into the matrix; bias[co]
-            for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw) for (int co = 0; co < Co; ++co) for (int ci = 0; ci < Ci; ++ci)
+            // (ci runs over the reference's channels; a stage whose input is padded to whole chunks keeps zero rows for the pads)
+            for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw) for (int co = 0; co < Co; ++co) for (int ci = 0; ci < st.cin_real; ++ci)
                 xfer(I[(size_t)(((k - 1 - kh) * k + (k - 1 - kw)) * Ci + ci) * d.ld + co]);
             for (int co = 0; co < Co; ++co) xfer(I[(size_t)K * d.ld + co]);
         } else {
@@ -584,9 +648,14 @@ struct Builder {
         w.kin = d.in; w.aux1 = p<unsigned char>(d.W) + (size_t)d.in * d.ldw * h->es; w.ld1 = d.ldw;   // bias row (see WorkItem::bias_ep)
         return w;
     }
-    WorkItem fwd_head(const Mod& md, bool with_z) {
+    WorkItem fwd_head(const Mod& md, bool with_z, bool implicit = false) {
         const Act& in = md.conv ? md.cenc[3].P : md.E.back();
         WorkItem w = gemm_item(K_FWD_HEAD, B, 2 * h->nz, K_of(md.head.in + 1), p<void>(in.rm), in.ld, p<void>(md.head.Wt), md.head.ldt);
+        if (implicit) {          // conv encoder: the flattened 3x3 map, gathered by the GEMM itself
+            ConvGeom g = md.cenc[3].g; g.B = B;
+            w.A = p<void>(h->off_consts); w.lda = 0;
+            w.conv = add_conv(g, p<void>(md.cenc[2].Y.rm), true);
+        }
         w.nz = h->nz;
         w.out0 = p<void>(md.mulv); w.ld0 = 2 * h->nz;
         w.out1 = with_z ? p<void>(md.Z.rm) : nullptr; w.ld1 = md.Z.ld;
@@ -594,7 +663,7 @@ struct Builder {
         return w;
     }
     WorkItem fwd_out(const Mod& md, int m, bool loss) {
-        const Act& in = md.conv ? md.cdec[4].P : md.D.back();
+        const Act& in = md.conv ? (md.cdec[3].dense_map ? md.cdec[3].Y : md.cdec[4].P) : md.D.back();
         WorkItem w = gemm_item(loss ? K_FWD_OUT_LOSS : K_FWD_OUT_STORE, B, md.n_in, K_of(md.outl.in + 1), p<void>(in.rm), in.ld,
                                p<void>(md.outl.Wt), md.outl.ldt);
         w.binary = h->cfg.mod[m].binary ? 1 : 0;
@@ -697,6 +766,7 @@ struct Builder {
         t.Y = p<void>(st.Y.rm); t.ldy = st.Y.ld;
         t.act = st.act; t.act_in = prev.act;
         t.dY = p<void>(st.dY.rm); t.lddy = st.dY.ld;
+        if (st.dense_map) { t.img_y = st.Y.ld; t.ldy = 1; t.img_dy = st.dY.ld; t.lddy = 1; }      // dense rows: pixel stride 1, image stride = row stride
         t.dX = p<void>(prev.dY.rm); t.lddx = prev.dY.ld;
         t.part = p<float>(st.thin_part); t.Kp = st.thin_kp;
         return t;
@@ -741,6 +811,65 @@ struct Builder {
         const int R = B * st.g.IH * st.g.IW;
         tile_shape(R, C, &c.cl, &c.rpt, &c.tiles_r, &c.tiles_c);
         return c;
+    }
+    // ---- implicit-GEMM routes (ConvA): descriptors are appended to the handle's table, items carry the 1-based index
+    static unsigned magic(int x) { return x <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)x) + 1u; }
+    int add_conv(const ConvGeom& g, const void* src, bool ones) {
+        ConvA c;
+        std::memset(&c, 0, sizeof(c));
+        c.src = src; c.consts = p<void>(h->off_consts);
+        c.M = g.B * g.OH * g.OW; c.K = g.k * g.k * g.Cin;
+        c.OHW = g.OH * g.OW; c.OW = g.OW; c.IH = g.IH; c.IW = g.IW; c.Cin = g.Cin;
+        c.k = g.k; c.so = g.so; c.d = g.d; c.pad = g.pad; c.src_sb = g.src_sb; c.src_sp = g.src_sp; c.ones = ones ? 1 : 0;
+        c.mg_ohw = magic(c.OHW); c.mg_ow = magic(c.OW); c.mg_k = magic(c.k); c.mg_cin = magic(c.Cin);
+        if ((c.d != 1 && c.d != 2) || (c.so != 1 && c.so != 2)) throw Err("internal error: implicit conv geometry (strides 1 and 2 only)");
+        if ((size_t)h->conv_tab.size() >= 4 * (size_t)kMaxConvA * kMaxMod) throw Err("internal error: too many implicit patch matrices");
+        h->conv_tab.push_back(c);
+        return (int)h->conv_tab.size();
+    }
+    // forward of stage `st` on the map `src` (strides in st.g): Y = act(P . W_aug), P implicit
+    WorkItem conv_fwd_impl(const ConvStage& st, const void* src) {
+        ConvGeom g = st.g; g.B = B;
+        WorkItem w = gemm_item(K_FWD_HIDDEN, conv_rows(st), st.d.out, K_of(st.d.in + 1), p<void>(h->off_consts), 0, p<void>(st.d.Wt), st.d.ldt);
+        w.act = st.act;
+        w.out0 = p<void>(st.Y.rm); w.ld0 = st.Y.ld;
+        w.conv = add_conv(g, src, st.bias);
+        return w;
+    }
+    // adjoint geometry of stage `st`: rows = its input pixels, source = its output gradient `dY` (element strides sb / sp)
+    ConvGeom adj_geom(const ConvStage& st, int sb, int sp) const {
+        const ConvGeom& f = st.g;
+        return ConvGeom{B, f.OH, f.OW, st.d.out, f.IH, f.IW, f.k, f.d, f.so, f.k - 1 - f.pad, sb, sp, 0};
+    }
+    // input gradient of stage `st` as an implicit GEMM on its output gradient: dX = (Padj . Wadj^T) * act'(stored input)
+    WorkItem adj_dgrad_impl(const ConvStage& st, const void* dY, int sb, int sp, int prev_act, const Act& prevY, const Act& prevdY) {
+        const int rows = B * st.g.IH * st.g.IW, KA = st.g.k * st.g.k * st.d.out;
+        WorkItem w = gemm_item(K_DGRAD_HIDDEN, rows, st.g.Cin, K_of(KA), p<void>(h->off_consts), 0, p<void>(st.Wadj), st.ldadj);
+        w.act = prev_act;
+        w.aux0 = p<void>(prevY.rm); w.ldx = prevY.ld;
+        w.out0 = p<void>(prevdY.rm); w.ld0 = prevdY.ld;
+        w.conv = add_conv(adj_geom(st, sb, sp), dY, false);
+        return w;
+    }
+    // the first decoder stage's input is z: its input gradient takes the latent epilogue (dz -> [dmu | dlv], reparameterisation)
+    WorkItem adj_dgrad_latent_impl(const ConvStage& st, const Mod& md) {
+        const int KA = st.g.k * st.g.k * st.d.out;
+        WorkItem w = gemm_item(K_DGRAD_LATENT, B, h->nz, K_of(KA), p<void>(h->off_consts), 0, p<void>(st.Wadj), st.ldadj);
+        w.nz = h->nz;
+        w.aux2 = p<void>(md.g0);
+        w.out0 = p<void>(md.dH.rm); w.ld0 = md.dH.ld;
+        w.conv = add_conv(adj_geom(st, st.g.OH * st.g.OW * st.dY.ld, st.dY.ld), p<void>(st.dY.rm), false);
+        return w;
+    }
+    // filter gradient of stage `st`: dW_aug = P^T . dA with P implicit (K-major operand of the weight-gradient kernel)
+    WorkItem wgrad_impl(const ConvStage& st, const void* src, const Act& dA) {
+        ConvGeom g = st.g; g.B = B;
+        const int rows = conv_rows(st);
+        WorkItem w = gemm_item(K_WGRAD, st.d.in + 1, st.d.out, K_of(rows), p<void>(h->off_consts), 0, p<void>(dA.rm), dA.ld);
+        w.out0 = h->grad() + st.d.master; w.ld0 = st.d.ld;
+        if (st.ksplit > 1) { w.ksplit = st.ksplit; w.kchunk = st.kchunk; w.out1 = p<void>(st.part); }
+        w.conv = add_conv(g, src, st.bias);
+        return w;
     }
     // dW_aug[m][n] = sum_k X_aug[k][m] * dA[k][n]: both operands are read as stored (row = sample k), see the K-major
     // ("TN") images in avae_kernels.hip; rows >= batch of either buffer are zero padding
@@ -793,7 +922,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         const WorkItem& w = items[i];
         if ((w.kind == K_FWD_HEAD || w.kind == K_DGRAD_LATENT) && 2 * w.nz > 64) need128 = true;
         if (is_gemm(w.kind)) tiles128 += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
-        if (is_gemm(w.kind) && (w.N <= 64 || w.M <= 64)) narrow = true;      // a 128-wide tile would be mostly padding
+        if (is_gemm(w.kind) && (w.N <= 64 || w.M <= 64 || w.conv > 0)) narrow = true;      // a 128-wide tile would be mostly padding (implicit patch matrices: small tiles only)
     }
     L.cfg = (need128 || (tiles128 >= 192 && !narrow)) ? 1 : 0;
     {   // 256x128 tiles, 8 waves, one workgroup per CU: a third more flops per operand byte pulled from L2 into LDS,
@@ -824,15 +953,15 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
             bool lean = true;
             const int k0 = items[first].kind, a0 = items[first].act;
             for (int i = first; i < first + count; ++i)
-                lean = lean && items[i].kind == k0 && items[i].act == a0 && !items[i].bias_ep && items[i].K > 0;
+                lean = lean && items[i].kind == k0 && items[i].act == a0 && !items[i].bias_ep && items[i].K > 0 && items[i].conv == 0;
             if (lean && (k0 == K_FWD_HIDDEN || k0 == K_DGRAD_HIDDEN)) L.cfg = 7;
             bool store = true;                                    // the inference / serving output launch: k_small's third kind
-            for (int i = first; i < first + count; ++i) store = store && items[i].kind == K_FWD_OUT_STORE && !items[i].bias_ep && items[i].K > 0;
+            for (int i = first; i < first + count; ++i) store = store && items[i].kind == K_FWD_OUT_STORE && !items[i].bias_ep && items[i].K > 0 && items[i].conv == 0;
             if (store) L.cfg = 7;
             bool loss = false, only_loss = true;                  // the output + loss launch (with the latent item riding in it): k_small_loss
             for (int i = first; i < first + count; ++i) {
                 loss = loss || items[i].kind == K_FWD_OUT_LOSS;
-                only_loss = only_loss && ((items[i].kind == K_FWD_OUT_LOSS && !items[i].bias_ep && items[i].K > 0) || items[i].kind == K_LATENT);
+                only_loss = only_loss && ((items[i].kind == K_FWD_OUT_LOSS && !items[i].bias_ep && items[i].K > 0 && items[i].conv == 0) || items[i].kind == K_LATENT);
             }
             if (L.cfg == 5 && loss && only_loss && !std::getenv("AVAE_NO_LEAN_LOSS")) L.cfg = 9;
         }
@@ -856,6 +985,8 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         }
         if (loss_only && t >= 192) L.cfg = 6;
     }
+    for (int i = first; i < first + count; ++i)
+        if (items[i].conv > 0 && !(L.cfg == 0 || L.cfg == 3 || L.cfg == 5)) throw Err("internal error: an implicit patch matrix on a tile configuration without the gather");
     const int T = (L.cfg == 1 || L.cfg == 2 || L.cfg == 4) ? 128 : (L.cfg == 5 || L.cfg == 7 || L.cfg == 9) ? 32 : 64;
     const int TM = (L.cfg == 2 || L.cfg == 6) ? 256 : (L.cfg == 3 || L.cfg == 5 || L.cfg == 7 || L.cfg == 9) ? 32 : L.cfg == 4 ? 64 : T;
     if ((L.cfg == 2 || L.cfg == 6) && !std::getenv("AVAE_NO_BIAS_EP"))      // 8-wave NT tiles: bias in the epilogue where that saves a K tile
@@ -929,7 +1060,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
                 t.bias_row = std::max(w.bias_row, 0);
                 t.M = w.bias_row > 0 ? w.M - 1 : w.M; t.N = w.N; t.K = w.K; t.lda = w.lda; t.ldb = w.ldb; t.ld0 = w.ld0;
                 t.tiles_m = w.tiles_m; t.tiles_n = w.tiles_n; t.ksplit = w.ksplit; t.kchunk = w.kchunk;
-                t.tile_off = off; t.tile_cnt = std::min(SX, nt - off);
+                t.tile_off = off; t.tile_cnt = std::min(SX, nt - off); t.conv = w.conv;
             }
         }
         if (G > 1 && !std::getenv("AVAE_NO_TN_BALANCE")) {
@@ -976,6 +1107,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
         L.args.grid_x = L.grid_x;
         for (int i = 0; i < count; ++i) L.args.items[i] = items[first + i];
     }
+    L.args.conv_tab = L.targs.conv_tab = h->at<ConvA>(h->off_conv_tab);
     if (const char* e = std::getenv("AVAE_SCHED")) L.args.sched = L.targs.sched = std::atoi(e);
     if (*next_slot > h->n_partial) throw Err("internal error: cost partial slots overflow");
     return L;
@@ -984,7 +1116,7 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
 void dp_ranges(const avae_handle* h, int* n_buckets, std::vector<avae_handle::Range> (&out)[2]);
 
 void build_training_plan(avae_handle* h) {
-    h->items.clear(); h->fwd.clear(); h->bwd.clear(); h->wgrad.clear();
+    h->items.clear(); h->fwd.clear(); h->bwd.clear(); h->wgrad.clear(); h->conv_tab.clear();
     Builder bd(h, h->items, h->B, true);
     int slot = 0;
     int Lmax = 0;
@@ -1103,16 +1235,19 @@ void build_training_plan(avae_handle* h) {
         group("fwd_enc" + std::to_string(k + 1), h->fwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.X0 : md.E[k - 1], md.enc[k], md.E[k]));
         });
-    if (any_conv) {   // conv encoder: (im2col, GEMM) x 3, then the patch matrix of the flatten+dense heads
+    if (any_conv) {   // conv encoder: three convs, then the flatten + dense heads.  Per modality and stage: implicit GEMM (the patch
+                      // matrix is gathered by the GEMM's own operand loads), or im2col launch + GEMM where the channels are no whole chunks
         for (int i = 0; i < 3; ++i) {
+            auto src_of = [&, i](Mod& md) { return i == 0 ? h->at<void>(md.X0.rm) : h->at<void>(md.cenc[i - 1].Y.rm); };
             gather_launch("conv_enc" + std::to_string(i + 1) + "_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cenc[i]; },
-                          [&](Mod& md) { return i == 0 ? h->at<void>(md.X0.rm) : h->at<void>(md.cenc[i - 1].Y.rm); }, every_conv);
-            group("conv_enc" + std::to_string(i + 1), h->fwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_fwd(md.cenc[i])); });
+                          src_of, [i](const Mod& md) { return !md.cenc[i].impl; });
+            group("conv_enc" + std::to_string(i + 1), h->fwd, [&] {
+                for (Mod& md : h->mods) if (md.conv) h->items.push_back(md.cenc[i].impl ? bd.conv_fwd_impl(md.cenc[i], src_of(md)) : bd.conv_fwd(md.cenc[i])); });
         }
         gather_launch("conv_head_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cenc[3]; },
-                      [&](Mod& md) { return h->at<void>(md.cenc[2].Y.rm); }, every_conv);
+                      [&](Mod& md) { return h->at<void>(md.cenc[2].Y.rm); }, [](const Mod& md) { return !md.cenc[3].impl; });
     }
-    group("fwd_head", h->fwd, [&] { for (Mod& md : h->mods) h->items.push_back(bd.fwd_head(md, true)); });
+    group("fwd_head", h->fwd, [&] { for (Mod& md : h->mods) h->items.push_back(bd.fwd_head(md, true, md.conv && md.cenc[3].impl)); });
     // KL + association terms and their (mu, lv) gradients need every modality's (mu, lv) (ready after fwd_head) and are needed by
     // bwd_dec1_latent.  Small nets: they ride in the fwd_out_loss launch (the decoder's hidden launches stay plain GEMM launches).
     // Big nets, whose loss launch runs one 144-KB workgroup per CU on the 8-wave tile: there the item's workgroups would each take a
@@ -1149,10 +1284,12 @@ void build_training_plan(avae_handle* h) {
         L.blocks = base;
         if (base > 0 && std::getenv("AVAE_NO_WADJ_FOLD")) h->fwd.push_back(L);       // default: k_adam writes these shadows (AdamItem::Wadj)
     }
-    if (any_conv) {   // deconv decoder: (im2col of the dilated input, GEMM + bias + sigmoid) x 4, then flatten for the dense output
+    if (any_conv) {   // deconv decoder: four transposed convs (+ bias + sigmoid each), then the dense output layer
         for (int i = 0; i < 4; ++i) {
-            // every modality routes its stage i on its own (depths differ between modalities): direct, adjoint frame or patch matrix
-            auto plain = [&](const Mod& md) { return !md.cdec[i].thin && !md.cdec[i].adj; };
+            // every modality routes its stage i on its own (depths differ between modalities): direct (one output channel), implicit
+            // GEMM in gather form, round 2's adjoint-frame scatter product, or im2col + GEMM
+            auto plain = [&, i](const Mod& md) { return !md.cdec[i].thin && !md.cdec[i].adj && !md.cdec[i].impl; };
+            auto src_of = [&, i](Mod& md) { return i == 0 ? h->at<void>(md.Z.rm) : h->at<void>(md.cdec[i - 1].Y.rm); };
             if (is_thin(i)) thin_launch("conv_dec" + std::to_string(i + 1) + "_direct", h->fwd, 0, i);
             if (is_adj(i)) {       // scatter product on the stage's (small) input, then overlap-add + bias + transfer function
                 group("conv_dec" + std::to_string(i + 1) + "_scatter", h->fwd, [&] {
@@ -1168,12 +1305,15 @@ void build_training_plan(avae_handle* h) {
                 L.blocks = base;
                 h->fwd.push_back(L);
             }
-            gather_launch("conv_dec" + std::to_string(i + 1) + "_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
-                          [&](Mod& md) { return i == 0 ? h->at<void>(md.Z.rm) : h->at<void>(md.cdec[i - 1].Y.rm); }, plain);
-            group("conv_dec" + std::to_string(i + 1), h->fwd, [&] { for (Mod& md : h->mods) if (md.conv && plain(md)) h->items.push_back(bd.conv_fwd(md.cdec[i])); });
+            gather_launch("conv_dec" + std::to_string(i + 1) + "_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; }, src_of, plain);
+            group("conv_dec" + std::to_string(i + 1), h->fwd, [&] {
+                for (Mod& md : h->mods) if (md.conv) {
+                    if (md.cdec[i].impl) h->items.push_back(bd.conv_fwd_impl(md.cdec[i], src_of(md)));
+                    else if (plain(md)) h->items.push_back(bd.conv_fwd(md.cdec[i]));
+                } });
         }
         gather_launch("conv_out_im2col", h->fwd, [&](Mod& md) -> const ConvStage& { return md.cdec[4]; },
-                      [&](Mod& md) { return h->at<void>(md.cdec[3].Y.rm); }, every_conv);
+                      [&](Mod& md) { return h->at<void>(md.cdec[3].Y.rm); }, [](const Mod& md) { return !md.cdec[3].dense_map; });
     }
     group("fwd_out_loss", h->fwd, [&] {
         for (int m = 0; m < h->M; ++m) h->items.push_back(bd.fwd_out(h->mods[m], m, true));
@@ -1184,52 +1324,70 @@ void build_training_plan(avae_handle* h) {
     // producing stage).
     group("bwd_out", h->bwd, [&] {
         for (Mod& md : h->mods) {
-            if (md.conv) h->items.push_back(bd.conv_dgrad(md.cdec[4], md.dO));
+            if (md.conv && md.cdec[3].dense_map) {      // the 28x28 map is a dense row: an ordinary dense dgrad, sigmoid' of the stored map
+                const ConvStage& s3 = md.cdec[3];
+                WorkItem w = bd.dgrad_hidden(md.dO, md.outl, s3.Y, s3.dY);
+                w.act = s3.act;
+                h->items.push_back(w);
+            }
+            else if (md.conv) h->items.push_back(bd.conv_dgrad(md.cdec[4], md.dO));
             else h->items.push_back(bd.dgrad_hidden(md.dO, md.outl, md.D.back(), md.dD.back()));
         }
     });
+    bool latent_conv_impl = false;          // some conv modality's first decoder stage takes the implicit latent dgrad (rides in bwd_dec1_latent)
     if (any_conv) {
-        for (int i = 4; i >= 1; --i) {       // stage i's patch gradients -> dY of stage i-1; then stage i-1's dgrad GEMM
-            // (per modality; a direct or adjoint-frame stage has no patch gradients: its own launches wrote the producing
-            // stage's gradient)
-            auto plain_i = [&](const Mod& md) { return !md.cdec[i].thin && !md.cdec[i].adj; };
-            auto plain_j = [&](const Mod& md) { return !md.cdec[i - 1].thin && !md.cdec[i - 1].adj; };
+        for (int i = 4; i >= 1; --i) {       // stage i's patch gradients -> dY of stage i-1; then stage i-1's input gradient
+            // (per modality; a direct, adjoint-frame or implicit stage has no patch gradients: its own launch wrote the producing stage's gradient)
+            auto explicit_i = [&, i](const Mod& md) { return !md.cdec[i].thin && !md.cdec[i].adj && !md.cdec[i].impl_bwd && !(i == 4 && md.cdec[3].dense_map); };
+            auto plain_j = [&, i](const Mod& md) { return !md.cdec[i - 1].thin && !md.cdec[i - 1].adj && !md.cdec[i - 1].impl_bwd; };
             col2im_launch("conv_dec" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[i]; },
-                          [&](Mod& md) -> const ConvStage* { return &md.cdec[i - 1]; }, plain_i);
+                          [&](Mod& md) -> const ConvStage* { return &md.cdec[i - 1]; }, explicit_i);
             if (is_thin(i - 1)) thin_launch("conv_bwd_dec" + std::to_string(i) + "_direct", h->bwd, 1, i - 1);
             if (is_adj(i - 1)) {     // patch matrix of stage i-1's output gradient -> GEMM with the adjoint filter -> dY of stage i-2
                 Launch L;
                 L.name = "conv_bwd_dec" + std::to_string(i) + "_adj_im2col"; L.type = 1;
                 int base = 0;
-                for (Mod& md : h->mods) if (md.conv && md.cdec[i - 1].adj) {
+                for (Mod& md : h->mods) if (md.conv && md.cdec[i - 1].adj && (!md.cdec[i - 1].impl_bwd || !md.cdec[i - 1].impl_w)) {      // (Padj feeds the adjoint dgrad and the adjoint-frame filter gradient)
                     GatherSeg g = bd.adj_gather_seg(md.cdec[i - 1]);
                     g.tile_base = base; base += g.tiles_r * g.tiles_c;
                     L.ga.seg[L.ga.n_seg++] = g;
                 }
                 L.blocks = base;
-                h->bwd.push_back(L);
+                if (base > 0) h->bwd.push_back(L);
                 group("conv_bwd_dec" + std::to_string(i) + "_adj", h->bwd, [&] {
-                    for (Mod& md : h->mods) if (md.conv && md.cdec[i - 1].adj) h->items.push_back(bd.adj_dgrad(md.cdec[i - 1], md.cdec[i - 2])); });
+                    for (Mod& md : h->mods) if (md.conv && md.cdec[i - 1].adj && !md.cdec[i - 1].impl_bwd) h->items.push_back(bd.adj_dgrad(md.cdec[i - 1], md.cdec[i - 2])); });
             }
             group("conv_bwd_dec" + std::to_string(i), h->bwd, [&] {
-                for (Mod& md : h->mods) if (md.conv && plain_j(md)) h->items.push_back(bd.conv_dgrad(md.cdec[i - 1], md.cdec[i - 1].dY)); });
+                for (Mod& md : h->mods) if (md.conv) {
+                    const ConvStage& st = md.cdec[i - 1];
+                    if (st.impl_bwd && i - 1 >= 1)          // implicit GEMM on stage i-1's own output gradient: writes dY of stage i-2
+                        h->items.push_back(bd.adj_dgrad_impl(st, h->at<void>(st.dY.rm), st.g.OH * st.g.OW * st.dY.ld, st.dY.ld, md.cdec[i - 2].act, md.cdec[i - 2].Y, md.cdec[i - 2].dY));
+                    else if (st.impl_bwd) latent_conv_impl = true;
+                    else if (plain_j(md)) h->items.push_back(bd.conv_dgrad(st, st.dY));
+                } });
         }
         // first decoder stage: its input is z -> latent mode turns dz into [dmu | dlv]
         col2im_launch("conv_dec1_latent", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cdec[0]; },
-                      [&](Mod&) -> const ConvStage* { return nullptr; }, every_conv);
+                      [&](Mod&) -> const ConvStage* { return nullptr; }, [](const Mod& md) { return !md.cdec[0].impl_bwd; });
     }
     for (int k = Lmax - 1; k >= 1; --k)
         group("bwd_dec" + std::to_string(k + 1), h->bwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.dgrad_hidden(md.dD[k], md.dec[k], md.D[k - 1], md.dD[k - 1]));
         });
     group("bwd_dec1_latent", h->bwd, [&] {
-        for (Mod& md : h->mods) if (!md.conv) h->items.push_back(bd.dgrad_latent(md));
+        for (Mod& md : h->mods) {
+            if (!md.conv) h->items.push_back(bd.dgrad_latent(md));
+            else if (md.cdec[0].impl_bwd) h->items.push_back(bd.adj_dgrad_latent_impl(md.cdec[0], md));
+        }
         h->items.push_back(bd.cost(true));                       // every cost partial is final since fwd_out_loss: cost, step counter, lr_t
     });
+    (void)latent_conv_impl;
     h->bwd_split = (int)h->bwd.size();      // everything from here on belongs to the encoder side
     group("bwd_head", h->bwd, [&] {
         for (Mod& md : h->mods) {
-            if (md.conv) h->items.push_back(bd.conv_dgrad(md.cenc[3], md.dH));
+            if (md.conv && md.cenc[3].impl_bwd)     // implicit: the heads' input gradient straight into the 3x3 map's gradient rows
+                h->items.push_back(bd.adj_dgrad_impl(md.cenc[3], h->at<void>(md.dH.rm), md.dH.ld, md.dH.ld, md.cenc[2].act, md.cenc[2].Y, md.cenc[2].dY));
+            else if (md.conv) h->items.push_back(bd.conv_dgrad(md.cenc[3], md.dH));
             else h->items.push_back(bd.dgrad_hidden(md.dH, md.head, md.E.back(), md.dE.back()));
         }
     });
@@ -1237,8 +1395,13 @@ void build_training_plan(avae_handle* h) {
     if (any_conv) {
         for (int i = 3; i >= 1; --i) {
             col2im_launch("conv_enc" + std::to_string(i) + "_col2im", h->bwd, [&](Mod& md) -> const ConvStage& { return md.cenc[i]; },
-                          [&](Mod& md) -> const ConvStage* { return &md.cenc[i - 1]; }, every_conv);
-            if (i >= 2) group("conv_bwd_enc" + std::to_string(i), h->bwd, [&] { for (Mod& md : h->mods) if (md.conv) h->items.push_back(bd.conv_dgrad(md.cenc[i - 1], md.cenc[i - 1].dY)); });
+                          [&](Mod& md) -> const ConvStage* { return &md.cenc[i - 1]; }, [i](const Mod& md) { return !md.cenc[i].impl_bwd; });
+            if (i >= 2) group("conv_bwd_enc" + std::to_string(i), h->bwd, [&] {
+                for (Mod& md : h->mods) if (md.conv) {
+                    const ConvStage& st = md.cenc[i - 1];
+                    if (st.impl_bwd) h->items.push_back(bd.adj_dgrad_impl(st, h->at<void>(st.dY.rm), st.g.OH * st.g.OW * st.dY.ld, st.dY.ld, md.cenc[i - 2].act, md.cenc[i - 2].Y, md.cenc[i - 2].dY));
+                    else h->items.push_back(bd.conv_dgrad(st, st.dY));
+                } });
         }
     }
     for (int k = Lmax - 1; k >= 1; --k) {
@@ -1252,11 +1415,25 @@ void build_training_plan(avae_handle* h) {
     // Safe: every buffer is written once per step, so a product may run any time between its inputs' writers and its readers.
     if (any_conv && !std::getenv("AVAE_NO_SINK")) {
         auto plain_kind = [](int k) { return k == K_FWD_HIDDEN || k == K_DGRAD_HIDDEN || k == K_DGRAD_F32; };
+        // only launches of the MLP modalities move: an item that writes a conv modality's buffer stays where the plan put it (its readers
+        // include helper launches -- the direct stage, im2col / col2im -- that the dependency scan below does not look into)
+        std::vector<const void*> conv_bufs;
+        for (const Mod& md : h->mods) if (md.conv) {
+            for (const Act* a : {&md.Z, &md.dH, &md.dO}) conv_bufs.push_back(h->at<void>(a->rm));
+            for (const std::vector<ConvStage>* side : {&md.cenc, &md.cdec})
+                for (const ConvStage& st : *side) { conv_bufs.push_back(h->at<void>(st.Y.rm)); conv_bufs.push_back(h->at<void>(st.dY.rm)); }
+        }
+        auto mlp_item = [&](const WorkItem& w) {
+            if (w.conv > 0) return false;
+            for (const void* q : conv_bufs) if (q == w.out0 || q == w.A) return false;
+            return true;
+        };
         auto reads = [&](const Launch& L, const std::vector<const void*>& outs) {
             if (L.type != 0) return false;                  // the conv helper launches touch the conv modality's buffers only
             for (int i = 0; i < L.count; ++i) {
                 const WorkItem& w = h->items[L.first + i];
-                for (const void* q : {w.A, w.B, w.aux0, w.aux1, w.aux2, (const void*)w.tail_w, (const void*)w.tail_aux})
+                const void* csrc = w.conv > 0 ? h->conv_tab[w.conv - 1].src : nullptr;      // (an implicit patch matrix reads its source map)
+                for (const void* q : {w.A, w.B, w.aux0, w.aux1, w.aux2, (const void*)w.tail_w, (const void*)w.tail_aux, csrc})
                     for (const void* o : outs) if (q && q == o) return true;
             }
             return false;
@@ -1269,7 +1446,7 @@ void build_training_plan(avae_handle* h) {
                 std::vector<const void*> outs;
                 for (int i = 0; i < P.count; ++i) {
                     const WorkItem& w = h->items[P.first + i];
-                    movable = movable && (w.kind == K_FWD_HIDDEN || w.kind == K_DGRAD_HIDDEN) && !w.bias_ep;
+                    movable = movable && (w.kind == K_FWD_HIDDEN || w.kind == K_DGRAD_HIDDEN) && !w.bias_ep && mlp_item(w);
                     outs.push_back(w.out0);
                 }
                 if (!movable) continue;
@@ -1312,7 +1489,7 @@ void build_training_plan(avae_handle* h) {
                 std::vector<const void*> ins;
                 for (int i = 0; i < P.count; ++i) {
                     const WorkItem& w = h->items[P.first + i];
-                    movable = movable && (w.kind == K_FWD_HIDDEN || w.kind == K_DGRAD_HIDDEN) && !w.bias_ep;
+                    movable = movable && (w.kind == K_FWD_HIDDEN || w.kind == K_DGRAD_HIDDEN) && !w.bias_ep && mlp_item(w);
                     ins.push_back(w.A);
                 }
                 if (!movable) continue;
@@ -1352,14 +1529,22 @@ void build_training_plan(avae_handle* h) {
         std::vector<WorkItem> wg;
         for (Mod& md : h->mods) {
             if (md.conv) {
-                wg.push_back(bd.wgrad_stage(md.cdec[4], md.dO));
+                if (md.cdec[3].dense_map) wg.push_back(bd.wgrad(md.cdec[3].Y, md.cdec[4].d, md.dO));       // the dense output layer on the dense map
+                else wg.push_back(bd.wgrad_stage(md.cdec[4], md.dO));
                 for (int i = 3; i >= 0; --i) {
-                    if (md.cdec[i].thin) continue;
-                    if (md.cdec[i].adj) wg.push_back(bd.adj_wgrad(md.cdec[i], md.cdec[i - 1]));
-                    else wg.push_back(bd.wgrad_stage(md.cdec[i], md.cdec[i].dY));
+                    const ConvStage& st = md.cdec[i];
+                    if (st.thin) continue;
+                    if (st.impl_w) wg.push_back(bd.wgrad_impl(st, i == 0 ? h->at<void>(md.Z.rm) : h->at<void>(md.cdec[i - 1].Y.rm), st.dY));
+                    else if (st.adj) wg.push_back(bd.adj_wgrad(st, md.cdec[i - 1]));
+                    else wg.push_back(bd.wgrad_stage(st, st.dY));
                 }
-                wg.push_back(bd.wgrad_stage(md.cenc[3], md.dH));
-                for (int i = 2; i >= 0; --i) wg.push_back(bd.wgrad_stage(md.cenc[i], md.cenc[i].dY));
+                if (md.cenc[3].impl_w) wg.push_back(bd.wgrad_impl(md.cenc[3], h->at<void>(md.cenc[2].Y.rm), md.dH));
+                else wg.push_back(bd.wgrad_stage(md.cenc[3], md.dH));
+                for (int i = 2; i >= 0; --i) {
+                    const ConvStage& st = md.cenc[i];
+                    if (st.impl_w) wg.push_back(bd.wgrad_impl(st, i == 0 ? h->at<void>(md.X0.rm) : h->at<void>(md.cenc[i - 1].Y.rm), st.dY));
+                    else wg.push_back(bd.wgrad_stage(st, st.dY));
+                }
                 continue;
             }
             wg.push_back(bd.wgrad(md.D.back(), md.outl, md.dO));
@@ -1371,7 +1556,7 @@ void build_training_plan(avae_handle* h) {
         }
         // big problems: the narrow products (heads, first decoder layer) get launches of their own, or their presence
         // would hold the wide ones on 64x64 tiles (finish_launch picks one tile shape per launch)
-        auto is_narrow = [](const WorkItem& w) { return w.N <= 64 || w.M <= 64; };
+        auto is_narrow = [](const WorkItem& w) { return w.N <= 64 || w.M <= 64 || w.conv > 0; };    // (implicit patch matrices: small tiles only)
         auto wgrad_launches = [&](const std::vector<WorkItem>& set, std::vector<Launch>& dst, const std::string& prefix) {
             long wide128 = 0;
             for (const WorkItem& w : set) if (!is_narrow(w)) wide128 += (long)((w.M + 127) / 128) * ((w.N + 127) / 128);
@@ -1423,7 +1608,7 @@ void build_training_plan(avae_handle* h) {
             Launch L;
             L.name = "conv_bias_rowsum"; L.type = 8;
             int base = 0;
-            for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {
+            for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj && !st.impl_w) {
                 RowsumSeg& g = L.rs.seg[L.rs.n_seg++];
                 g.src = h->at<void>(st.dY.rm); g.part = h->at<float>(st.rs_part); g.ld = st.dY.ld;
                 g.rows = h->B * st.g.OH * st.g.OW; g.cols = st.d.out; g.cols4 = st.rs_cols4; g.n_blocks = kRowsumBlocks;
@@ -1438,7 +1623,7 @@ void build_training_plan(avae_handle* h) {
             Launch R;
             R.name = "conv_wgrad_sums"; R.type = 5;
             int base = 0;
-            for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {      // second level of the row sums
+            for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj && !st.impl_w) {      // second level of the row sums
                 ReduceSeg& g = R.ra.seg[R.ra.n_seg++];
                 g.dst = h->grad() + st.d.master + (size_t)st.d.in * st.d.ld; g.src = h->at<float>(st.rs_part);
                 g.n = st.d.out; g.parts = kRowsumBlocks; g.stride = st.rs_cols4; g.dst_ld = 1;
@@ -1483,7 +1668,7 @@ void build_training_plan(avae_handle* h) {
             Launch L;
             L.name = "conv_wgrad_perm"; L.type = 7;
             int base = 0;
-            for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj) {
+            for (Mod& md : h->mods) if (md.conv) for (const ConvStage& st : md.cdec) if (st.adj && !st.impl_w) {
                 if (st.aksplit > 1 && !std::getenv("AVAE_NO_SUMS_MERGE")) continue;      // permuted by its slice sum (ReduceSeg::perm_*)
                 GpermSeg& g = L.gp.seg[L.gp.n_seg++];
                 g.Gadj = h->at<float>(st.Gadj); g.G = h->grad() + st.d.master; g.ldga = st.ldga; g.ld = st.d.ld;
@@ -1575,14 +1760,17 @@ void build_training_plan(avae_handle* h) {
     };
     for (const Mod& md : h->mods) {
         if (md.conv) {
-            for (const ConvStage& st : md.cenc) add(st.d);
-            for (const ConvStage& st : md.cdec) {
-                add(st.d);
-                if (st.adj && !std::getenv("AVAE_NO_WADJ_FOLD")) {       // adjoint filter shadows by the same pass (no k_wadj launch)
-                    AdamItem& a = h->adam_items.back();
-                    a.Wadj = h->at<void>(st.Wadj); a.Wf = h->at<void>(st.Wf); a.ldadj = st.ldadj; a.ldf = st.ldf; a.adj_k = st.g.k; a.adj_cin = st.g.Cin;
+            for (const std::vector<ConvStage>* side : {&md.cenc, &md.cdec})
+                for (const ConvStage& st : *side) {
+                    add(st.d);
+                    // adjoint filter shadows by the same pass (no k_wadj launch): the implicit input gradients' B operand, and -- round 2's
+                    // adjoint-frame route -- the forward scatter product's
+                    if ((st.adj && !std::getenv("AVAE_NO_WADJ_FOLD")) || st.impl_bwd) {
+                        AdamItem& a = h->adam_items.back();
+                        a.Wadj = h->at<void>(st.Wadj); a.ldadj = st.ldadj; a.adj_k = st.g.k; a.adj_cin = st.g.Cin;
+                        if (st.adj) { a.Wf = h->at<void>(st.Wf); a.ldf = st.ldf; }
+                    }
                 }
-            }
             continue;
         }
         for (const Dense& d : md.enc) add(d);
@@ -1646,10 +1834,21 @@ void build_inference(avae_handle* h, int m, bool enc, int rows) {
         one(bd.fwd_head(md, true), "inf_head");
     } else if (md.conv) {
         for (int i = 0; i < 4; ++i) {
+            if (md.cdec[i].dense_map) {      // the one-channel 28x28 stage writes dense rows: the direct kernel, as in training
+                Launch L;
+                L.name = "inf_conv_dec_direct"; L.type = 4;
+                L.ta.mode = 0;
+                ThinSeg t = bd.thin_seg(md.cdec[i], md.cdec[i - 1]);
+                t.block_base = 0;
+                L.ta.seg[0] = t; L.ta.n_seg = 1;
+                L.blocks = rows * kThinSplit;
+                inf.launches.push_back(L);
+                continue;
+            }
             gather1(md.cdec[i], i == 0 ? h->at<void>(md.Z.rm) : h->at<void>(md.cdec[i - 1].Y.rm), "inf_conv_im2col");
             one(bd.conv_fwd(md.cdec[i]), "inf_conv_dec");
         }
-        gather1(md.cdec[4], h->at<void>(md.cdec[3].Y.rm), "inf_conv_im2col");
+        if (!md.cdec[3].dense_map) gather1(md.cdec[4], h->at<void>(md.cdec[3].Y.rm), "inf_conv_im2col");
         one(bd.fwd_out(md, m, false), "inf_out");
     } else {
         for (int k = 0; k < md.L; ++k) one(bd.fwd_hidden(k == 0 ? md.Z : md.D[k - 1], md.dec[k], md.D[k]), "inf_dec");
@@ -1899,10 +2098,23 @@ void init_device(avae_handle* h) {
         for (const Act& a : md.E) fill_ones(h, a, s);
         fill_ones(h, md.Z, s);
         for (const Act& a : md.D) fill_ones(h, a, s);
+        if (md.conv && md.cdec[3].dense_map) fill_ones(h, md.cdec[3].Y, s);      // the dense 28x28 map feeds the output layer: its bias column
     }
     build_training_plan(h);
     HIP_OK(hipMemcpyAsync(h->at<void>(h->off_adam), h->adam_items.data(), h->adam_items.size() * sizeof(AdamItem), hipMemcpyHostToDevice, s));
     HIP_OK(hipMemcpyAsync(h->at<void>(h->off_adam_b), h->adam_items_b.data(), h->adam_items_b.size() * sizeof(AdamItem), hipMemcpyHostToDevice, s));
+    {   // the two constant chunks an implicit patch matrix reads instead of an invalid tap / as its bias column, and the descriptors
+        static const unsigned char c32_bf16[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x80, 0x3F};         // bf16 1.0 = 0x3F80, little endian
+        static const unsigned char c32_f32[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x80, 0x3F};      // fp32 1.0 = 0x3F800000
+        HIP_OK(hipMemcpyAsync(h->at<void>(h->off_consts), h->es == 2 ? c32_bf16 : c32_f32, 32, hipMemcpyHostToDevice, s));
+        if (!h->conv_tab.empty()) {
+            const unsigned char* lo = h->ws + h->stage_lo;
+            for (const ConvA& c : h->conv_tab)
+                if (reinterpret_cast<const unsigned char*>(c.src) >= lo && reinterpret_cast<const unsigned char*>(c.src) < lo + h->stage_bytes * kMultiSteps)
+                    throw Err("internal error: an implicit patch matrix on a staged input (not relocatable per step)");
+            HIP_OK(hipMemcpyAsync(h->at<void>(h->off_conv_tab), h->conv_tab.data(), h->conv_tab.size() * sizeof(ConvA), hipMemcpyHostToDevice, s));
+        }
+    }
     size_t off = h->off_inf;
     h->inf_enc.assign(h->M, avae_handle::Inf());
     h->inf_dec.assign(h->M, avae_handle::Inf());

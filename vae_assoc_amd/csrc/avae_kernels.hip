@@ -533,6 +533,38 @@ extern __shared__ __attribute__((aligned(16))) unsigned char avae_dyn_smem[];
 template <bool TN> struct ArgsOf { typedef LaunchArgs type; };
 template <> struct ArgsOf<true> { typedef TnLaunchArgs type; };
 
+// ---- implicit patch matrix (ConvA, avae_device.h): address of the 16-byte chunk P[m][kk ..] a lane stages
+__device__ __forceinline__ unsigned mg_div(unsigned n, unsigned mg) { return mg ? __umulhi(n, mg) : n; }     // mg = 0: divisor 1
+struct ConvRow { const unsigned char* base; int hs, ws; bool ok; };     // row m = (b, oh, ow): image base, oh*so - pad, ow*so - pad
+struct ConvTap { int kh, kw, ci, kind; };                                // column kk = (kh, kw, ci); kind 1: the ones chunk, 2: zeros
+template <int ES> __device__ __forceinline__ ConvRow conv_row(const ConvA& c, int m) {
+    ConvRow r;
+    r.ok = m < c.M;
+    const unsigned mm = r.ok ? (unsigned)m : 0u;
+    const unsigned b = mg_div(mm, c.mg_ohw), rem = mm - b * (unsigned)c.OHW, oh = mg_div(rem, c.mg_ow), ow = rem - oh * (unsigned)c.OW;
+    r.base = reinterpret_cast<const unsigned char*>(c.src) + (size_t)b * c.src_sb * ES;
+    r.hs = (int)oh * c.so - c.pad; r.ws = (int)ow * c.so - c.pad;
+    return r;
+}
+__device__ __forceinline__ ConvTap conv_tap(const ConvA& c, int kk) {
+    ConvTap t;
+    t.kind = kk < c.K ? 0 : (kk == c.K && c.ones ? 1 : 2);
+    const unsigned k2 = t.kind ? 0u : (unsigned)kk;
+    const unsigned kp = mg_div(k2, c.mg_cin), kh = mg_div(kp, c.mg_k);
+    t.ci = (int)(k2 - kp * (unsigned)c.Cin); t.kh = (int)kh; t.kw = (int)(kp - kh * (unsigned)c.k);
+    return t;
+}
+template <int ES> __device__ __forceinline__ const unsigned char* conv_addr(const ConvA& c, const ConvRow& r, const ConvTap& t) {
+    const unsigned char* z = reinterpret_cast<const unsigned char*>(c.consts);
+    if (t.kind) return z + (t.kind == 1 && r.ok ? 16 : 0);
+    const int nh = r.hs + t.kh, nw = r.ws + t.kw;
+    bool ok = r.ok && nh >= 0 && nw >= 0;
+    int ih = nh, iw = nw;
+    if (c.d == 2) { ok = ok && !((nh | nw) & 1); ih = nh >> 1; iw = nw >> 1; }     // (the branch uses strides 1 and 2 only; the host checks)
+    ok = ok && ih < c.IH && iw < c.IW;
+    return ok ? r.base + ((size_t)(ih * c.IW + iw) * c.src_sp + t.ci) * ES : z;
+}
+
 __device__ __forceinline__ WorkItem item_of(const LaunchArgs& args, int y) { return args.items[y]; }
 __device__ __forceinline__ WorkItem item_of(const TnLaunchArgs& args, int y) {
     const TnItem ti = args.items[y];
@@ -540,7 +572,7 @@ __device__ __forceinline__ WorkItem item_of(const TnLaunchArgs& args, int y) {
     w.kind = K_WGRAD;
     w.M = ti.M; w.N = ti.N; w.K = ti.K; w.lda = ti.lda; w.ldb = ti.ldb; w.ld0 = ti.ld0;
     w.tiles_m = ti.tiles_m; w.tiles_n = ti.tiles_n; w.ksplit = ti.ksplit; w.kchunk = ti.kchunk; w.bias_row = ti.bias_row;
-    w.tile_off = ti.tile_off; w.tile_cnt = ti.tile_cnt;
+    w.tile_off = ti.tile_off; w.tile_cnt = ti.tile_cnt; w.conv = ti.conv;
     w.A = ti.A; w.B = ti.B; w.out0 = ti.out; w.out1 = ti.out;
     return w;
 }
@@ -685,6 +717,18 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
     const int dwave = NP > 0 ? (wave >= NW ? wave - NW : 0) : wave;      // index among the issuing waves
     const unsigned char* src[NCH];
     size_t kadv[NCH];                                                    // bytes from one K tile to the next (TN: EPR rows)
+    // Implicit patch matrix as the A operand (ConvA): on the small tiles only (conv stages have <= 64 output channels or are
+    // forced onto these tiles by the host).  The A pieces of an issuing wave are its first NA pieces.
+    constexpr bool IMPL = BM <= 64 && NP == 0 && (BM / 8) % NDW == 0;
+    constexpr int NA = IMPL ? (BM / 8) / NDW : 1;
+    bool impl = false;
+    ConvA cv = {};
+    ConvRow crow[NA];                                                    // NT: the piece's row (fixed over K)
+    ConvTap ctap[NA];                                                    // TN: the piece's column chunk (fixed over K)
+    int cpos[NA];                                                        // NT: element offset of the chunk inside a K tile; TN: row inside a K tile
+    if constexpr (IMPL) {
+        if (w.conv > 0) { impl = true; cv = args.conv_tab[w.conv - 1]; }
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int r = (c * NDW + dwave) * 8 + (lane >> 3);              // row of the (A part, then B part) tile image
@@ -696,10 +740,12 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
             const size_t ld_b = is_a ? lda_b : ldb_b;
             kadv[c] = (size_t)EPR * ld_b;
             src[c] = (is_a ? Ag : Bg) + (size_t)k * ld_b + (size_t)sub * kTileBytesK + lc * 16 + (size_t)k_first * kadv[c];
+            if constexpr (IMPL) { if (impl && c < NA) { ctap[c] = conv_tap(cv, m0 + sub * EPR + lc * (16 / ES)); cpos[c] = k_first * EPR + k; } }
         } else {
             const int lc = (lane & 7) ^ ((r >> 1) & 7);                 // logical chunk this lane fetches
             src[c] = (r < BM ? Ag + (size_t)r * lda_b : Bg + (size_t)(r - BM) * ldb_b) + lc * 16;
             kadv[c] = kTileBytesK;
+            if constexpr (IMPL) { if (impl && c < NA) { crow[c] = conv_row<ES>(cv, m0 + r); cpos[c] = lc * (16 / ES); } }
         }
     }
 #ifdef AVAE_STAMPS_PRO
@@ -730,9 +776,15 @@ __global__ void __launch_bounds__((NW + NP) * 64, (RING == 2 ? 2 : 1)) k_grouped
 
 #define AVAE_DMA(kt, buf)                                                                              \
     {                                                                                                  \
-        _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                                \
-            __builtin_amdgcn_global_load_lds((gp_t)(src[c] + (size_t)(kt) * (TN ? kadv[c] : (size_t)kTileBytesK)), \
+        _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                              \
+            const unsigned char* sp_ = src[c] + (size_t)(kt) * (TN ? kadv[c] : (size_t)kTileBytesK);   \
+            if constexpr (IMPL) { if (impl && c < NA) {     /* implicit patch matrix: this lane's chunk of K tile kt */ \
+                if constexpr (TN) sp_ = conv_addr<ES>(cv, conv_row<ES>(cv, cpos[c] + (kt) * EPR), ctap[c]); \
+                else sp_ = conv_addr<ES>(cv, crow[c], conv_tap(cv, (kt) * EPR + cpos[c]));              \
+            } }                                                                                        \
+            __builtin_amdgcn_global_load_lds((gp_t)sp_,                                                \
                 (lp_t)(smem + (buf) * TileSmem<BM, BN, RING>::kStage + (c * NDW + dwave_u) * 1024), 16, 0, 0); \
+        }                                                                                              \
     }
 #define AVAE_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #ifdef AVAE_ABL_NO_DMA      /* diagnostic: loop without the operand refills (results are garbage) */
@@ -2157,7 +2209,7 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
                     if (gcol + e < w.cols) {
                         const CT v = to_ct<CT>(th[e]);
                         reinterpret_cast<CT*>(w.Wadj)[(size_t)ci * w.ldadj + r + e] = v;
-                        reinterpret_cast<CT*>(w.Wf)[(size_t)(r + e) * w.ldf + ci] = v;
+                        if (w.Wf) reinterpret_cast<CT*>(w.Wf)[(size_t)(r + e) * w.ldf + ci] = v;
                     }
             }
         }
@@ -2593,14 +2645,14 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
     if (a.mode != 2)                                      // filter taps (+ bias at K)
         for (int i = tid; i < K + 1; i += kThreads) sf[i] = ct_load<CT>(F + i);
     if (a.mode != 0) {                                    // output-gradient map
-        const CT* dY = reinterpret_cast<const CT*>(w.dY) + (size_t)b * npo * w.lddy;
+        const CT* dY = reinterpret_cast<const CT*>(w.dY) + (size_t)b * (w.img_dy > 0 ? w.img_dy : npo * w.lddy);
         for (int i = tid; i < npo; i += kThreads) sdy[i] = ct_load<CT>(dY + (size_t)i * w.lddy);
     }
     lds_barrier();
 
     if (a.mode == 0) {
         // Y[oh, ow] = act(bias + sum over taps (kh, kw) with ih = (oh*so + kh - pad)/d an integer in [0, IH) (same for w))
-        CT* Y = reinterpret_cast<CT*>(w.Y) + (size_t)b * npo * w.ldy;
+        CT* Y = reinterpret_cast<CT*>(w.Y) + (size_t)b * (w.img_y > 0 ? w.img_y : npo * w.ldy);
         const int p_end = min(npo, (sub + 1) * ((npo + kThinSplit - 1) / kThinSplit));
         for (int p = sub * ((npo + kThinSplit - 1) / kThinSplit) + tid; p < p_end; p += kThreads) {
             const int oh = p / g.OW, ow = p - oh * g.OW;
