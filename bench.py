@@ -544,6 +544,7 @@ def main():
     one_gpu = world > 1 and os.environ.get("AVAE_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+        os.environ.setdefault("AVAE_IPC_BLOCKS", "64")       # the ranks' spinning exchange kernels share one GPU: all of them must be resident
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

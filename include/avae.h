@@ -200,6 +200,9 @@ int avae_synchronize(avae_handle* h);
  * one-store kernel timed the same way.  Report: one line "<name> <calls> <avg_ms> <min_ms>" per launch. */
 int avae_timing_enable(avae_handle* h, int32_t on);
 int avae_timing_report(avae_handle* h, char* buf, size_t buf_bytes);
+/* The gradient collective of bucket `bucket` alone, on `stream` (micro-benchmarks and tests of the exchange; the train calls run it
+ * on the library's comm stream inside the step).  Every rank must make the same sequence of calls. */
+int avae_comm_allreduce(avae_handle* h, int32_t bucket, void* stream);
 /* Copies a named internal tensor to the host as fp32 (tests): "mulv<m>" [batch,2*n_z], "eps" [batch,n_z], "E<m>_<k>" / "D<m>_<k>" the
  * stored output of encoder / decoder hidden layer k of modality m [batch, width] (the last forward pass's relu decisions). */
 int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t max_floats, size_t* n_floats);

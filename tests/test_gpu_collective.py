@@ -47,7 +47,7 @@ def _shard(X, eps, world, rank, s):
 
 
 def _worker(rank, world, port, out_dir, variants):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AVAE_IPC_TIMEOUT_MS="8000")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AVAE_IPC_TIMEOUT_MS="8000", AVAE_IPC_BLOCKS="64")    # (several ranks share ONE GPU here: their spinning exchange kernels must all be resident)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import __graft_entry__ as g
@@ -178,3 +178,56 @@ def test_bf16_wire_on_the_rccl_path_one_rank():
     assert np.abs(g1 - g0).max() <= 2e-2 * np.abs(g0).max()
     as_bf16 = torch.as_tensor(g1.astype(np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
     assert np.array_equal(as_bf16, g1.astype(np.float32)), "what Adam consumed is exactly representable in bf16"
+
+
+def _vector_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AVAE_IPC_TIMEOUT_MS="8000", AVAE_IPC_BLOCKS=str(256 // world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        import __graft_entry__ as g
+        g.build()
+        from vae_assoc_amd import _capi
+        from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
+        L = _capi.lib()
+        worst = {}
+        for wire in ("fp32", "bf16"):
+            for nb in (1, 2):
+                m = AssocVariationalAutoEncoder(ARCHS, batch_size=32, compute_dtype="bf16", device=0, data_parallel=True, comm="ipc", comm_buckets=nb,
+                                                wire_dtype=wire, **KW)
+                n_el = m._grad_view.numel()
+                srcs = [np.random.default_rng(100 + r).standard_normal(n_el).astype(np.float32) for r in range(world)]
+                want = np.sum([s.astype(np.float64) for s in srcs], axis=0)
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for rep in range(3):                       # the sequence numbers / flags / slots are reused call after call
+                    m._grad_view.copy_(torch.as_tensor(srcs[rank]))
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    for b in range(nb):
+                        assert L.avae_comm_allreduce(m._h, b, st) == 0
+                    m.synchronize()
+                    got = m._grad_view.cpu().numpy().astype(np.float64)
+                    d = np.abs(got - want)
+                    tol = 1e-6 if wire == "fp32" else 8e-3          # bf16: 2^-9 per term of the sum, once more on the rounded result
+                    assert d[-1] <= 1e-6 * max(1.0, abs(want[-1])), "the cost slot always travels as fp32"
+                    assert d.max() <= tol * np.abs(want).max(), (world, wire, nb, rep, float(d.max()), int(np.argmax(d)))
+                    worst["%s_%d" % (wire, nb)] = got
+                del m
+                dist.barrier()
+        np.savez(os.path.join(out_dir, "vec_r%d.npz" % rank), **worst)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_allreduce_kernel_on_random_vectors(tmp_path, world):
+    """The exchange kernel alone (avae_comm_allreduce) on dense random vectors, EVERY entry of the buffer checked against the fp64
+    sum, three calls in a row, fp32 and bf16 wire, one and two buckets, 128 / 64 workgroups per rank.  (A real gradient buffer has
+    zero pad columns; round 3's first kernel staged loads through inline asm whose data the compiler copied before it had landed --
+    2 % of the granules, invisible to the training parity tests until the loops around it changed.)  The replicas' results are
+    bit-identical."""
+    mp.spawn(_vector_worker, args=(world, _port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "vec_r%d.npz" % k)) for k in range(world)]
+    for key in r[0].files:
+        for k in range(1, world):
+            assert np.array_equal(r[0][key], r[k][key]), (key, k)

@@ -171,7 +171,7 @@ def _port():
 
 
 def _rank_worker(rank, world, port, out_dir, name, comms):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AVAE_IPC_TIMEOUT_MS="8000")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AVAE_IPC_TIMEOUT_MS="8000", AVAE_IPC_BLOCKS="64")    # (several ranks share ONE GPU here: their spinning exchange kernels must all be resident)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import __graft_entry__ as g

@@ -32,7 +32,7 @@ SYMBOLS = [
     "avae_train_step", "avae_train_steps", "avae_stage_batches", "avae_grad_buffer", "avae_cost_history",
     "avae_dp_plan", "avae_dp_backward", "avae_dp_apply", "avae_comm_unique_id", "avae_comm_ipc_handle", "avae_comm_ipc_attach",
     "avae_eval_cost", "avae_encode", "avae_decode", "avae_generate", "avae_reconstruct", "avae_save", "avae_load",
-    "avae_synchronize", "avae_timing_enable", "avae_timing_report", "avae_debug_fetch",
+    "avae_synchronize", "avae_timing_enable", "avae_timing_report", "avae_debug_fetch", "avae_comm_allreduce",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
             L.avae_timing_enable.argtypes = [vp, i32]
             L.avae_timing_report.argtypes = [vp, C.c_char_p, sz]
             L.avae_debug_fetch.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]
+            L.avae_comm_allreduce.argtypes = [vp, i32, vp]
             for name in SYMBOLS:
                 if name not in ("avae_destroy", "avae_last_error"):
                     getattr(L, name).restype = C.c_int

@@ -15,12 +15,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // exchange block -- and loads are served from memory, never from this XCD's L2 or the CU's L1.  The exchange blocks are uncached
 // allocations as well; the scope bits make the protocol independent of how an imported mapping is cached.
 __device__ __forceinline__ void store16_sys(void* p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+    // (s_nop 1 inside the string: hipcc does not pad an asm statement's hazards, and its next instruction may overwrite the data
+    // registers before a 16-byte store has read them -- the first 8 bytes of 2 % of the granules carried an address once)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
+// Loads are compiler-visible (two 8-byte relaxed system-scope atomic loads = global_load_dwordx2 sc0 sc1): an inline-asm load whose
+// wait is a separate statement is NOT safe -- the compiler believes the value is there when the asm statement ends and may copy the
+// destination registers before the data has landed (seen here: 2 % of the granules came back with a stale first half once the
+// surrounding loops were unrolled further; the parity tests on real gradients had passed).
 __device__ __forceinline__ u32x4 load16_sys(const void* p) {
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return u32x4{(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -46,10 +53,6 @@ __device__ __forceinline__ void drain_block() {
     wait_vm0();
     __syncthreads();
 }
-// The inline-asm loads above are invisible to the compiler's own wait counting: after wait_vm0() every loaded register passes through
-// settle(), which orders its first use behind the wait (register-only maths is otherwise free to move above an asm s_waitcnt).
-__device__ __forceinline__ void settle(u32x4& v) { asm volatile("" : "+v"(v)); }
-
 // Wave 0: lane r waits for flag[r] == seq (r != me), bounded.  Returns false after a timeout (error word raised).
 __device__ __forceinline__ bool wait_flags(const unsigned* flags, unsigned seq, int world, int me, unsigned long long timeout,
                                            unsigned* err, unsigned code) {
@@ -84,6 +87,7 @@ __global__ void __launch_bounds__(kIpcThreads) k_ipc_allreduce(IpcArgs a) {
     unsigned* seqp = reinterpret_cast<unsigned*>(mine + a.off_seq) + w;
     unsigned* err = reinterpret_cast<unsigned*>(mine + a.off_err);
     const unsigned seq = *seqp + 1u;                         // this call's number (the same on every rank: they make the same calls)
+    if (N == 1) { if (tid == 0) *seqp = seq; return; }       // the sum over one rank is the gradient as it stands (cost included)
     const long long S = (a.granules + N - 1) / N;            // granules per shard
     const long long C = (S + a.blocks - 1) / a.blocks;       // granules per (shard, workgroup) chunk
     auto shard_len = [&](int j) { const long long lo = (long long)j * S; return lo >= a.granules ? 0ll : (a.granules - lo < S ? a.granules - lo : S); };
@@ -97,10 +101,21 @@ __global__ void __launch_bounds__(kIpcThreads) k_ipc_allreduce(IpcArgs a) {
         const long long n = chunk_len(j);
         unsigned char* dst = a.peer[j] + a.off_slots + (long long)me * a.slot_stride + c0 * GB;
         const float* src = g + ((long long)j * S + c0) * 8;
-        for (long long i = tid; i < n; i += kIpcThreads) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(src + i * 8), hi = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
-            if (BF16) store16_sys(dst + i * 16, pack8(lo, hi));
-            else { store16_sys(dst + i * 32, __builtin_bit_cast(u32x4, lo)); store16_sys(dst + i * 32 + 16, __builtin_bit_cast(u32x4, hi)); }
+        constexpr int U1 = 4;                                   // granules per thread and trip: their loads are in flight together
+        for (long long i0 = tid; i0 < n; i0 += (long long)U1 * kIpcThreads) {
+            f32x4 lo[U1], hi[U1];
+#pragma unroll
+            for (int u = 0; u < U1; ++u) {
+                const long long i = i0 + (long long)u * kIpcThreads;
+                if (i < n) { lo[u] = *reinterpret_cast<const f32x4*>(src + i * 8); hi[u] = *reinterpret_cast<const f32x4*>(src + i * 8 + 4); }
+            }
+#pragma unroll
+            for (int u = 0; u < U1; ++u) {
+                const long long i = i0 + (long long)u * kIpcThreads;
+                if (i >= n) continue;
+                if (BF16) store16_sys(dst + i * 16, pack8(lo[u], hi[u]));
+                else { store16_sys(dst + i * 32, __builtin_bit_cast(u32x4, lo[u])); store16_sys(dst + i * 32 + 16, __builtin_bit_cast(u32x4, hi[u])); }
+            }
         }
         if (w == 0 && tid == 0 && a.cost_idx >= 0)            // the local cost, fp32, to every peer (workgroup 0's flags cover it)
             __hip_atomic_store(reinterpret_cast<float*>(a.peer[j] + a.off_cost) + me, a.g[a.cost_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -131,7 +146,6 @@ __global__ void __launch_bounds__(kIpcThreads) k_ipc_allreduce(IpcArgs a) {
                         }
                 }
             }
-            wait_vm0();
 #pragma unroll
             for (int u = 0; u < U2; ++u) {
                 const long long i = i0 + (long long)u * kIpcThreads;
@@ -144,9 +158,8 @@ __global__ void __launch_bounds__(kIpcThreads) k_ipc_allreduce(IpcArgs a) {
                         f32x4 xl, xh;
                         if (r == me) { xl = mlo; xh = mhi; }
                         else {
-                            settle(raw[u][r][0]);
                             if (BF16) unpack8(raw[u][r][0], xl, xh);
-                            else { settle(raw[u][r][BF16 ? 0 : 1]); xl = __builtin_bit_cast(f32x4, raw[u][r][0]); xh = __builtin_bit_cast(f32x4, raw[u][r][BF16 ? 0 : 1]); }
+                            else { xl = __builtin_bit_cast(f32x4, raw[u][r][0]); xh = __builtin_bit_cast(f32x4, raw[u][r][BF16 ? 0 : 1]); }
                         }
                         lo += xl; hi += xh;
                     }
@@ -193,15 +206,13 @@ __global__ void __launch_bounds__(kIpcThreads) k_ipc_allreduce(IpcArgs a) {
                         for (int q = 0; q < Q; ++q) p[u][q] = load16_sys(src + i * GB + 16 * q);
                     }
                 }
-                wait_vm0();
 #pragma unroll
                 for (int u = 0; u < U3; ++u) {
                     const long long i = i0 + (long long)u * kIpcThreads;
                     if (i >= n) continue;
                     f32x4 lo, hi;
-                    settle(p[u][0]);
                     if (BF16) unpack8(p[u][0], lo, hi);
-                    else { settle(p[u][Q - 1]); lo = __builtin_bit_cast(f32x4, p[u][0]); hi = __builtin_bit_cast(f32x4, p[u][Q - 1]); }
+                    else { lo = __builtin_bit_cast(f32x4, p[u][0]); hi = __builtin_bit_cast(f32x4, p[u][Q - 1]); }
                     *reinterpret_cast<f32x4*>(dst + i * 8) = lo; *reinterpret_cast<f32x4*>(dst + i * 8 + 4) = hi;
                 }
             }

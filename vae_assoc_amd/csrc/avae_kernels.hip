@@ -86,7 +86,7 @@ template <> __device__ __forceinline__ void store_vec<__bf16, 8>(__bf16* p, cons
         // through as they are issued take 2 us off every big forward launch and change nothing for the small ones.
         typedef __attribute__((ext_vector_type(4))) unsigned u4_;
         const u4_ raw = __builtin_bit_cast(u4_, t);
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(raw) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(raw) : "memory");   // (s_nop 1: the store must have read its data registers before hipcc's next instruction may write them)
         return;
     }
 #pragma unroll
@@ -434,7 +434,7 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ void store16_wt(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
     const u32x4 raw = {a, b, c, d};      // written through (sc0 sc1), as store_vec<__bf16, 8>: see there
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(raw) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(raw) : "memory");   // (s_nop 1: the store must have read its data registers before hipcc's next instruction may write them)
 }
 // Applies f(i, j, r, acc) to every accumulator element and stores the MI x NI blocks of this wave.  rbase = first row of the
 // wave's sub-tile + (lane & 15); cwave = first column of the wave's sub-tile.  EXEC must be full (the swaps cross lanes).
