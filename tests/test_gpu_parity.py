@@ -514,6 +514,27 @@ def test_lean_small_tile_kernel(V, monkeypatch, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B", [256, 100, 37])
+def test_chain2_experiment_is_bitwise(V, monkeypatch, dtype, B):
+    """VERDICT r2 #6 (AVAE_CHAIN2=1): fwd_enc1 -> fwd_enc2 in ONE launch behind a row-block-local hand-off (write-through stores, a
+    ticket per row block, sc1 loads) instead of a kernel boundary: the same tiles, K order and rounding points -- bitwise the two
+    launches' results, at the bench batch (8 row blocks = 8 XCDs) and at batches whose row blocks do not line up with the XCDs."""
+    archs = [make_arch("image", 784, 500, 500, 20), make_arch("joint", 147, 200, 200, 20)]
+    rng = np.random.default_rng(11)
+    X = synth_batch(rng, 20 * B, [784, 147], [True, False])
+    res = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv("AVAE_CHAIN2", "1")
+        m = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="relu", weights=[50, 1], assoc_lambda=8.0, batch_size=B,
+                                          compute_dtype=dtype, seed=1)
+        c0 = m.partial_fit([x[:B] for x in X])
+        m.partial_fit_steps([x[B:] for x in X], 19, return_cost=False)
+        res.append((c0, m.cost_history(20).copy(), m.get_params()))
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("nz", [32, 31, 5])
 def test_lean_head_kernels(V, monkeypatch, dtype, nz):
     """The two fused head launches of small nets on the lean frame (k_small_head: [mu | lv] -> z -> decoder's first layer;

@@ -413,5 +413,6 @@ void launch_small_tn(int compute_dtype, const TnLaunchArgs& args, int grid_x, in
 void launch_small_loss(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id);
 void launch_small(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, hipStream_t s, unsigned long long* stamps, int launch_id);
 void launch_reduce(const ReduceArgs& a, int n_blocks, hipStream_t s);
+void launch_chain2(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, unsigned* counters, unsigned* err, hipStream_t s);
 
 }  // namespace avae

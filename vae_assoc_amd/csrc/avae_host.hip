@@ -235,6 +235,7 @@ struct avae_handle {
                    ServeInArgs in_lean; int in_lean_grid = 0; bool lean_in = false; };
     std::vector<Serve> serve;
     size_t off_slot = 0;
+    size_t off_chain = 0;
     size_t off_consts = 0, off_conv_tab = 0;   // 32 B {zeros | one, 0...}; device copy of conv_tab
     std::vector<ConvA> conv_tab;             // implicit patch matrices of the training plan
 
@@ -565,6 +566,7 @@ void plan_memory(avae_handle* h) {
     h->off_adam_b = b.take(n_adam * sizeof(AdamItem));
     h->off_slot = b.take(sizeof(ServeSlot));
     h->off_consts = b.take(32);
+    h->off_chain = b.take((kMaxMod * 64 + 1) * 4);      // k_chain2: a ticket counter per (modality, row block), + its error word
     h->off_conv_tab = b.take(4 * kMaxConvA * kMaxMod * sizeof(ConvA));
     h->off_inf = b.off;
     for (int m = 0; m < h->M; ++m) b.take(2 * ((size_t)h->mods[m].L + 1) * sizeof(WorkItem));
@@ -1235,6 +1237,26 @@ void build_training_plan(avae_handle* h) {
         group("fwd_enc" + std::to_string(k + 1), h->fwd, [&] {
             for (Mod& md : h->mods) if (k < md.L) h->items.push_back(bd.fwd_hidden(k == 0 ? md.X0 : md.E[k - 1], md.enc[k], md.E[k]));
         });
+    // Experiment (AVAE_CHAIN2=1): fwd_enc1 and fwd_enc2 of the small nets as ONE launch behind a row-block-local hand-off
+    // (k_chain2) instead of a kernel boundary.  Needs both on the lean 32x32 kernel, equal widths (the same tile grid) and whole quads.
+    if (std::getenv("AVAE_CHAIN2") && !any_conv && h->fwd.size() == 2 && h->fwd[0].cfg == 7 && h->fwd[1].cfg == 7 && h->fwd[0].count == h->fwd[1].count
+        && 2 * h->fwd[0].count <= kMaxItemsPerLaunch) {
+        Launch& A = h->fwd[0];
+        const Launch& Bn = h->fwd[1];
+        bool ok = true;
+        for (int i = 0; i < A.count; ++i) {
+            const WorkItem& a = A.args.items[i];
+            const WorkItem& c = Bn.args.items[i];
+            ok = ok && a.kind == K_FWD_HIDDEN && c.kind == K_FWD_HIDDEN && a.act == c.act && a.M == c.M && a.N == c.N && a.tiles_m == c.tiles_m && a.tiles_n == c.tiles_n
+                    && c.A == a.out0 && c.lda == a.ld0 && a.N % 4 == 0 && a.tiles_m <= 64;
+        }
+        if (ok) {
+            for (int i = 0; i < A.count; ++i) A.args.items[A.count + i] = Bn.args.items[i];
+            A.args.n_items = 2 * A.count;
+            A.cfg = 13; A.name += "+" + Bn.name;
+            h->fwd.pop_back();
+        }
+    }
     if (any_conv) {   // conv encoder: three convs, then the flatten + dense heads.  Per modality and stage: implicit GEMM (the patch
                       // matrix is gathered by the GEMM's own operand loads), or im2col launch + GEMM where the channels are no whole chunks
         for (int i = 0; i < 3; ++i) {
@@ -1904,6 +1926,7 @@ void run_launches(avae_handle* h, const std::vector<Launch>& ls, hipStream_t s, 
         else if (L.type == 7) launch_gperm(L.gp, L.blocks, s);
         else if (L.type == 8) launch_rowsum(h->cfg.compute_dtype, L.rs, L.blocks, s);
         else if (L.type == 9) launch_sums(L.ra, L.blocks, s);
+        else if (L.cfg == 13) launch_chain2(h->cfg.compute_dtype, L.args, L.grid_x, L.grid_y, L.lds, h->at<unsigned>(h->off_chain), h->at<unsigned>(h->off_chain) + kMaxMod * 64, s);
         else if (L.cfg == 11) launch_small_head(h->cfg.compute_dtype, L.lean_act, L.args, L.grid_x, L.grid_y, L.lds, s, stamps, stamp_base + k);
         else if (L.cfg == 10) launch_small_latb(h->cfg.compute_dtype, L.lean_act, L.args, L.grid_x, L.grid_y, L.lds, h->state(), s, stamps, stamp_base + k);
         else if (L.cfg == 9) launch_small_loss(h->cfg.compute_dtype, L.args, L.grid_x, L.grid_y, L.lds, s, stamps, stamp_base + k);

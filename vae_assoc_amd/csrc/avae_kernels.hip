@@ -2091,6 +2091,132 @@ void launch_small(int compute_dtype, const LaunchArgs& args, int grid_x, int gri
     else { if (kind) launch_small_act<float, 1>(act, args, grid, lds_bytes, s, stamps, launch_id); else launch_small_act<float, 0>(act, args, grid, lds_bytes, s, stamps, launch_id); }
 }
 
+// ------------------------------------------------------------------ experiment: two chain links in ONE launch
+// fwd_enc1 -> fwd_enc2 of the small nets behind a row-block-local hand-off instead of a kernel boundary.  A tile (tm, tn) of layer 2
+// needs the 32 rows tm of layer 1, i.e. the tiles_n tiles of its own row block -- with batch 256 that is 8 row blocks, and the lean
+// kernels' tile order already gives an XCD the 16 (7) column tiles of ONE row block.  Workgroup (tm, tn) computes its layer-1 tile,
+// stores it write-through (sc1: nothing of it is left dirty in this XCD's L2), drains its stores, takes a ticket on the row block's
+// counter (agent-scope atomic; monotonic over launches: no reset), polls until the block's tiles_n tickets of this launch are in
+// (bounded spin), then computes its layer-2 tile from the handed-off rows (first touch of those lines in this kernel: the CU's L1
+// cannot hold them; the LDS-DMA loads carry sc1 as well).  Placement decides speed only: tickets and sc1 accesses are agent-scope.
+// Items: args.items[y] = layer 1 of modality y, args.items[n_items/2 + y] = layer 2.  AVAE_CHAIN2=1 turns it on (A/B).
+template <typename CT, int ACT>
+__global__ void __launch_bounds__(kThreads) k_chain2(const LaunchArgs args, unsigned* counters, unsigned* err) {
+    constexpr int BM = 32, RING = 4, ES = (int)sizeof(CT);
+    constexpr int kStage = 64 * kTileBytesK;
+    unsigned char* smem = avae_dyn_smem;
+    const int part = blockIdx.x & 7, idx = blockIdx.x >> 3, half = args.n_items >> 1;
+    const WorkItem w1 = args.items[blockIdx.y], w2 = args.items[half + blockIdx.y];
+    asm volatile("" :: "s"(w1.A), "s"(w1.B), "s"(w1.out0), "s"(w1.lda), "s"(w1.ldb), "s"(w1.K), "s"(w1.ld0), "s"(w2.B), "s"(w2.out0), "s"(w2.ldb), "s"(w2.K), "s"(w2.ld0));
+    int t;
+    {
+        const int nt = w1.tiles_m * w1.tiles_n;
+        const int q = nt >> 3, r = nt & 7;
+        if (idx >= q + (part < r ? 1 : 0)) return;
+        t = (part < r ? part * (q + 1) : r * (q + 1) + (part - r) * q) + idx;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tm = t / w1.tiles_n, tn = t - tm * w1.tiles_n;
+    const int m0 = tm * BM, n0 = tn * 32;
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    const int prow = wave * 8 + (lane >> 3), lc = ((lane & 7) ^ ((prow >> 1) & 7)) * 16;
+    const int sw0 = (fq ^ (fr >> 1)) * 16;
+    const int aoff = (wr * 16 + fr) * kTileBytesK, boff = (32 + wc * 16 + fr) * kTileBytesK;
+    const int orow = m0 + wr * 16 + fr, ocol = n0 + wc * 16 + 4 * fq;
+    f32x4 acc;
+#define AVAE_C_LOOP(W, AUX)                                                                                               \
+    {                                                                                                                     \
+        const unsigned char* srcA = reinterpret_cast<const unsigned char*>((W).A) + (size_t)(m0 + prow) * (W).lda * ES + lc;   \
+        const unsigned char* srcB = reinterpret_cast<const unsigned char*>((W).B) + (size_t)(n0 + prow) * (W).ldb * ES + lc;   \
+        const int nk = ((W).K * ES) / kTileBytesK;                                                                        \
+        auto dma = [&](int kt, int buf) __attribute__((always_inline)) {                                                  \
+            __builtin_amdgcn_global_load_lds((gp_t)(srcA + (size_t)kt * kTileBytesK), (lp_t)(smem + buf * kStage + wave * 1024), 16, 0, AUX);       \
+            __builtin_amdgcn_global_load_lds((gp_t)(srcB + (size_t)kt * kTileBytesK), (lp_t)(smem + buf * kStage + (4 + wave) * 1024), 16, 0, 0); };  \
+        const int npro = nk < RING - 1 ? nk : RING - 1;                                                                   \
+        for (int p = 0; p < npro; ++p) dma(p, p);                                                                         \
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                  \
+        int buf = 0;                                                                                                      \
+        for (int kt = 0; kt < nk; ++kt) {                                                                                 \
+            const int rem = nk - 1 - kt;                                                                                  \
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                \
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                           \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+            asm volatile("s_barrier" ::: "memory");                                                                       \
+            const unsigned char* Sb = smem + buf * kStage;                                                                 \
+            const u32x4 a0 = *reinterpret_cast<const u32x4*>(Sb + aoff + sw0), b0 = *reinterpret_cast<const u32x4*>(Sb + boff + sw0);   \
+            const int fill = buf == 0 ? RING - 1 : buf - 1;                                                               \
+            if (kt + RING - 1 < nk) dma(kt + RING - 1, fill);                                                             \
+            const u32x4 a1 = *reinterpret_cast<const u32x4*>(Sb + aoff + (sw0 ^ 64)), b1 = *reinterpret_cast<const u32x4*>(Sb + boff + (sw0 ^ 64)); \
+            mma<CT>(b0, a0, acc);                                                                                         \
+            mma<CT>(b1, a1, acc);                                                                                         \
+            buf = buf + 1 == RING ? 0 : buf + 1;                                                                          \
+        }                                                                                                                 \
+    }
+    // ---- link 1
+    AVAE_C_LOOP(w1, 0)
+    if (orow < w1.M && ocol < w1.N) {
+        CT* dst = reinterpret_cast<CT*>(w1.out0) + (size_t)orow * w1.ld0 + ocol;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fwd_t<ACT>(acc[e]);
+        if (w1.N - ocol >= 4) {          // the lane's 4 results as one write-through store (8 bytes of bf16, 16 of fp32)
+            if constexpr (ES == 2) {
+                const unsigned long long pk = (unsigned long long)pack_bf16(v[0], v[1]) | ((unsigned long long)pack_bf16(v[2], v[3]) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), __builtin_bit_cast(unsigned long long, float2{v[0], v[1]}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst) + 1, __builtin_bit_cast(unsigned long long, float2{v[2], v[3]}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            for (int e = 0; e < w1.N - ocol; ++e) {
+                if constexpr (ES == 2) __hip_atomic_store(reinterpret_cast<unsigned short*>(dst) + e, __builtin_bit_cast(unsigned short, to_ct<CT>(v[e])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_store(reinterpret_cast<float*>(dst) + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // ---- hand-off: every storing wave drains, the workgroup meets, one lane takes the ticket and polls for the row block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* cnt = counters + blockIdx.y * 64 + tm;           // (<= 64 row blocks per modality: the host checks)
+        const unsigned n = (unsigned)w1.tiles_n;
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (old / n + 1u) * n;
+        int spins = 0;
+        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // never hang: flag it and go on
+        }
+    }
+    __syncthreads();
+    // ---- link 2 on the handed-off rows (A = layer 1's output: sc1 on its LDS-DMA loads)
+    AVAE_C_LOOP(w2, 16)
+#undef AVAE_C_LOOP
+    if (orow < w2.M && ocol < w2.N) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fwd_t<ACT>(acc[e]);
+        store_row<CT>(reinterpret_cast<CT*>(w2.out0) + (size_t)orow * w2.ld0 + ocol, v, w2.N - ocol);
+    }
+}
+template <typename CT> static void launch_chain2_act(int act, const LaunchArgs& args, dim3 grid, int lds, unsigned* counters, unsigned* err, hipStream_t s) {
+    const dim3 block(kThreads);
+    switch (act) {
+    case AVAE_ACT_RELU: AVAE_LAUNCH((k_chain2<CT, AVAE_ACT_RELU>), grid, block, lds, s, args, counters, err); break;
+    case AVAE_ACT_SOFTPLUS: AVAE_LAUNCH((k_chain2<CT, AVAE_ACT_SOFTPLUS>), grid, block, lds, s, args, counters, err); break;
+    case AVAE_ACT_SIGMOID: AVAE_LAUNCH((k_chain2<CT, AVAE_ACT_SIGMOID>), grid, block, lds, s, args, counters, err); break;
+    case AVAE_ACT_TANH: AVAE_LAUNCH((k_chain2<CT, AVAE_ACT_TANH>), grid, block, lds, s, args, counters, err); break;
+    default: AVAE_LAUNCH((k_chain2<CT, AVAE_ACT_IDENTITY>), grid, block, lds, s, args, counters, err); break;
+    }
+}
+void launch_chain2(int compute_dtype, const LaunchArgs& args, int grid_x, int grid_y, int lds_bytes, unsigned* counters, unsigned* err, hipStream_t s) {
+    const dim3 grid(grid_x, grid_y);
+    if (compute_dtype == AVAE_BF16) launch_chain2_act<__bf16>(args.items[0].act, args, grid, lds_bytes, counters, err, s);
+    else launch_chain2_act<float>(args.items[0].act, args, grid, lds_bytes, counters, err, s);
+}
+
 // Refill-issuing waves of the 8-wave K-major (weight-gradient) tiles (see k_grouped).  Measured on C4: wgrad 143 -> 135 us with 4
 // producers; the NT tiles (hidden forward / dgrad) lost 1.5-3 us per launch with them (three waves per SIMD cap the kernel at
 // 168 VGPRs -- the register epilogue spills -- and their loop is paced by the arrival of the tiles either way), so they keep
