@@ -705,7 +705,7 @@ def test_transform_generate_reconstruct_rows(V):
     assert np.abs(model.get_params() - ref.get_params()).max() <= 2e-5
 
 
-@pytest.mark.parametrize("env", [{}, {"AVAE_NO_TAIL": "1"}])
+@pytest.mark.parametrize("env", [{}, {"AVAE_NO_TAIL": "1"}, {"AVAE_SERVE_GRAPH": "1"}, {"AVAE_SERVE_RING": "1"}])
 def test_generate_serving_buckets(V, monkeypatch, env):
     """avae_generate (per call: one staging launch that also runs the decoder's first layer as its tail product and publishes the
     call's slot, then one graph replay of the remaining decoder launches of every modality, whose output launch stores straight into

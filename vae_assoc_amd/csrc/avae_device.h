@@ -345,7 +345,11 @@ void launch_serve(int compute_dtype, const ServeArgs& a, const ServeSlot& call, 
 // k_serve_in: the staging launch that also runs the decoder's first layer (small nets)
 struct ServeInMod { const void* w; void* out; int n, ldw, ldo, kt, act, slices; };   // first decoder layer of one modality: weight shadow [n][ldw], output [bucket][ldo]
 struct ServeInArgs {
-    ServeSlot call;                // this call's pointers and row count
+    ServeSlot call;                // this call's pointers and row count (by value: the per-call eager launch)
+    const ServeSlot* rec;          // != null: read the call from this record instead -- a slot of the handle's pinned-host ring, written by
+                                   // the host just before it replays the graph this launch is the first node of (no eager launch per call)
+    unsigned long long* consumed;  // pinned-host word: number of ring records the device has read (the host's flow control)
+    unsigned long long* count;     // device-side counter behind it
     ServeSlot* slot;               // where the graph's output launch reads them
     int n_mod, nz, bucket, tiles_m;
     ServeInMod mod[kMaxMod];

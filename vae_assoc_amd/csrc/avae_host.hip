@@ -4,6 +4,7 @@
 #include "../../include/avae.h"
 
 #include <dlfcn.h>
+#include <sched.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -55,6 +56,7 @@ struct DeviceGuard {
         if (e_ != hipSuccess) throw Err(std::string("launch of ") + (what) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+constexpr int kServeRing = 16;         // call records in the serving path's pinned-host ring (= graphs per serving plan, one per slot)
 constexpr int kMultiSteps = 16;         // most whole steps per replay of a multi-step graph (avae_train_steps) = staging sets
 constexpr int kMultiSizes[2] = {16, 4};  // captured replay lengths: a run of n batches goes 16,16,...,4,4,...,1,1
 
@@ -232,9 +234,16 @@ struct avae_handle {
     // modalities, slot-indirect output move]
     struct Serve { int bucket = 0; std::vector<WorkItem> items; std::vector<Launch> launches; hipGraphExec_t graph = nullptr; ServeArgs in;
                    Launch in_launch; bool fused_in = false;
-                   ServeInArgs in_lean; int in_lean_grid = 0; bool lean_in = false; };
+                   ServeInArgs in_lean; int in_lean_grid = 0; bool lean_in = false;
+                   hipGraphExec_t ring_graph[kServeRing] = {}; };       // [staging launch reading ring record i, the plan's launches]
     std::vector<Serve> serve;
-    size_t off_slot = 0;
+    size_t off_slot = 0, off_serve_count = 0;
+    // Serving without a per-call eager launch: the call's record {z, rows, outputs} goes into a slot of a pinned-host ring and the
+    // graph of that slot is replayed -- its first kernel reads the record over PCIe.  `consumed` (pinned too) is the device's count
+    // of records read: the host never runs more than the ring ahead of it.
+    ServeSlot* serve_ring = nullptr;
+    unsigned long long* serve_consumed = nullptr;
+    unsigned long long serve_calls = 0;
     size_t off_chain = 0;
     size_t off_consts = 0, off_conv_tab = 0;   // 32 B {zeros | one, 0...}; device copy of conv_tab
     std::vector<ConvA> conv_tab;             // implicit patch matrices of the training plan
@@ -565,6 +574,7 @@ void plan_memory(avae_handle* h) {
     h->off_adam = b.take(n_adam * sizeof(AdamItem));
     h->off_adam_b = b.take(n_adam * sizeof(AdamItem));
     h->off_slot = b.take(sizeof(ServeSlot));
+    h->off_serve_count = b.take(8);
     h->off_consts = b.take(32);
     h->off_chain = b.take((kMaxMod * 64 + 1) * 4);      // k_chain2: a ticket counter per (modality, row block), + its error word
     h->off_conv_tab = b.take(4 * kMaxConvA * kMaxMod * sizeof(ConvA));
@@ -2323,6 +2333,7 @@ static_assert(kMaxWorld == AVAE_MAX_WORLD, "world size limit");
 void comm_streams(avae_handle* h) {
     int lo = 0, hi = 0;                          // the collective's kernels should start the moment their gradients exist
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (std::getenv("AVAE_COMM_NO_PRIO")) hi = 0;     // (A/B)
     HIP_OK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
     for (int b = 0; b < 2; ++b) {
         HIP_OK(hipEventCreateWithFlags(&h->ev_grad[b], hipEventDisableTiming));
@@ -2477,6 +2488,14 @@ void dp_allreduce(avae_handle* h, int b, hipStream_t cs) {
 
 // one step of the library-owned data-parallel pipeline on staging set j (main stream s, collective on the comm stream)
 void dp_step(avae_handle* h, int j, hipStream_t s, bool direct = false) {
+    if (h->n_buckets == 1) {
+        // one bucket: nothing to overlap, so everything stays on ONE stream -- a kernel on a second stream inside a captured graph
+        // costs fork / join edges (measured, one rank: 0.0583 -> see DESIGN section 6; the two-bucket pipeline pays 35 us for them)
+        dp_segment(h, j, 0, s, direct);
+        dp_allreduce(h, 0, s);
+        run_adam(h, 0, s, -1);
+        return;
+    }
     for (int b = 0; b < h->n_buckets; ++b) {
         dp_segment(h, j, b, s, direct);
         HIP_OK(hipEventRecord(h->ev_grad[b], s));
@@ -2641,7 +2660,8 @@ void avae_destroy(avae_handle* h) {
     (void)hipDeviceSynchronize();
     for (hipGraphExec_t g : {h->g_full, h->g_multi[0], h->g_multi[1], h->g_eval}) if (g) (void)hipGraphExecDestroy(g);
     for (int b = 0; b < 2; ++b) for (hipGraphExec_t g : h->g_dp[b]) if (g) (void)hipGraphExecDestroy(g);
-    for (avae_handle::Serve& sv : h->serve) if (sv.graph) (void)hipGraphExecDestroy(sv.graph);
+    for (avae_handle::Serve& sv : h->serve) { if (sv.graph) (void)hipGraphExecDestroy(sv.graph); for (hipGraphExec_t g : sv.ring_graph) if (g) (void)hipGraphExecDestroy(g); }
+    if (h->serve_ring) (void)hipHostFree(h->serve_ring);
     if (h->ev_switch) (void)hipEventDestroy(h->ev_switch);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
@@ -2995,6 +3015,55 @@ int avae_generate(avae_handle* h, const float* z_dev, int32_t rows, float* const
             std::memset(&sl, 0, sizeof(sl));
             sl.z = z_dev + (size_t)r0 * h->nz; sl.rows = n;
             for (int m = 0; m < h->M; ++m) sl.out[m] = xhat_dev[m] + (size_t)r0 * h->mods[m].n_in;
+            // Measured (tools/serve_latency.py, one box, 1 / 64 rows, C ABI back to back, us per call): staging launch + graph of the
+            // remaining launches 19.1 / 19.9 (host side 10.2: GPU-bound -- three dependent kernels and a replay boundary of ~5 us);
+            // every launch eager 14.6 / 15.6 (host-bound at 13.7 / 14.6: three launches) = the default since round 3; the pinned-host
+            // ring with the staging launch as the graph's first node (no eager launch: VERDICT r2 #9) 20.6 / 21.4 -- every workgroup
+            // of the first kernel reads the call record over PCIe, and the call was never host-bound.  AVAE_SERVE_GRAPH=1 /
+            // AVAE_SERVE_RING=1 select the other two for A/B.
+            static const bool use_ring = std::getenv("AVAE_SERVE_RING") != nullptr, eager = !use_ring && std::getenv("AVAE_SERVE_GRAPH") == nullptr;
+            if (sv.fused_in && sv.lean_in && eager) {          // no graph at all: the staging launch and the plan's launches, eagerly
+                sv.in_lean.call = sl;
+                launch_serve_in(h->cfg.compute_dtype, sv.in_lean, sv.in_lean_grid, s); LAUNCH_OK("serve_in+serve_dec1");
+                run_launches(h, sv.launches, s);
+                continue;
+            }
+            if (sv.fused_in && sv.lean_in && use_ring) {
+                // ONE graph replay per call: the record goes into the pinned ring, the slot's graph starts with the staging launch
+                if (!h->serve_ring) {
+                    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&h->serve_ring), kServeRing * sizeof(ServeSlot) + 64, hipHostMallocMapped | hipHostMallocPortable));
+                    std::memset(h->serve_ring, 0, kServeRing * sizeof(ServeSlot) + 64);
+                    h->serve_consumed = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(h->serve_ring) + kServeRing * sizeof(ServeSlot));
+                    HIP_OK(hipMemsetAsync(h->at<void>(h->off_serve_count), 0, 8, s));
+                }
+                const unsigned long long id = h->serve_calls;
+                const int slot = (int)(id % kServeRing);
+                // flow control: slot id % R was last used by call id - R; it is free once the device has STARTED call id - R + 1
+                // (calls run in order, so call id - R is over then)
+                while (id + 2 > __atomic_load_n(h->serve_consumed, __ATOMIC_ACQUIRE) + kServeRing) sched_yield();
+                h->serve_ring[slot] = sl;
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                if (!sv.ring_graph[slot]) {
+                    void* rec_dev = nullptr;
+                    void* con_dev = nullptr;
+                    HIP_OK(hipHostGetDevicePointer(&rec_dev, h->serve_ring + slot, 0));
+                    HIP_OK(hipHostGetDevicePointer(&con_dev, h->serve_consumed, 0));
+                    ServeInArgs ia = sv.in_lean;
+                    ia.rec = reinterpret_cast<const ServeSlot*>(rec_dev);
+                    ia.consumed = reinterpret_cast<unsigned long long*>(con_dev);
+                    ia.count = h->at<unsigned long long>(h->off_serve_count);
+                    const bool tsave = h->timing;
+                    h->timing = false;
+                    sv.ring_graph[slot] = capture(h, [&](hipStream_t cs) {
+                        launch_serve_in(h->cfg.compute_dtype, ia, sv.in_lean_grid, cs); LAUNCH_OK("serve_in+serve_dec1");
+                        run_launches(h, sv.launches, cs);
+                    });
+                    h->timing = tsave;
+                }
+                HIP_OK(hipGraphLaunch(sv.ring_graph[slot], s));
+                ++h->serve_calls;
+                continue;
+            }
             if (sv.fused_in && sv.lean_in) {
                 sv.in_lean.call = sl;
                 launch_serve_in(h->cfg.compute_dtype, sv.in_lean, sv.in_lean_grid, s); LAUNCH_OK("serve_in+serve_dec1");

@@ -2951,7 +2951,15 @@ __global__ void __launch_bounds__(kThreads) k_serve_in(ServeInArgs a) {
     if (tm >= a.tiles_m) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int m0 = tm * 32, nz = a.nz;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.slot = a.call;
+    // the call: by value in the kernel arguments (eager launch per call), or -- as the first node of a captured graph -- from the
+    // record the host wrote into its pinned ring before the replay (one uniform read over PCIe per workgroup)
+    ServeSlot call_v = a.call;
+    if (a.rec) call_v = *a.rec;
+    const ServeSlot& call = call_v;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        *a.slot = call;
+        if (a.rec) { const unsigned long long n = *a.count + 1; *a.count = n; __hip_atomic_store(a.consumed, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
     const int t_i = wave & 1, t_c0 = (2 * ts + (wave >> 1)) * 32, t_sl = 2 * md.kt;
     u32x4 tb[TSL][2];
 #pragma unroll
@@ -2965,13 +2973,13 @@ __global__ void __launch_bounds__(kThreads) k_serve_in(ServeInArgs a) {
     lds_barrier();
     {
         const int zrow = tid >> 3, zg = tid & 7;
-        if (m0 + zrow < a.call.rows) {
+        if (m0 + zrow < call.rows) {
             // every latent column: 8 threads per row take 4 columns each per trip (n_z up to 63 needs two trips)
             for (int d0 = 4 * zg; d0 < nz; d0 += 32) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int d = d0 + e;
-                    if (d < nz) img_put<CT>(img, zrow, d, a.call.z[(size_t)(m0 + zrow) * nz + d]);
+                    if (d < nz) img_put<CT>(img, zrow, d, call.z[(size_t)(m0 + zrow) * nz + d]);
                 }
             }
         }
