@@ -175,7 +175,6 @@ def conv_launch_work(archs, B, es):
     overlap-add, split-K reductions, adjoint filter shadows, permutes, row sums) do no algorithmic work: their time counts
     against the step, their bytes are overhead."""
     out = {}
-    no_impl = bool(os.environ.get("AVAE_NO_IMPLICIT"))
 
     def add(name, by, fl):
         b0, f0 = out.get(name, (0, 0))
@@ -200,11 +199,11 @@ def conv_launch_work(archs, B, es):
             bwd = {"enc1": [], "enc2": ["conv_bwd_enc2"], "enc3": ["conv_bwd_enc3"], "head": ["bwd_head"], "dec1": ["bwd_dec1_latent", "conv_dec1_latent"],
                    "dec2": ["conv_bwd_dec2", "conv_bwd_dec2_adj"], "dec3": ["conv_bwd_dec3", "conv_bwd_dec3_adj"], "dec4": ["conv_bwd_dec4_direct"], "out": ["bwd_out"]}[name]
             wgr = "conv_dec4_wgrad_direct" if name == "dec4" else "wgrad"
-            if no_impl:
-                fwd, bwd = fwd[-1:], bwd[-1:]
-            for nm in fwd[:1]:
+            # (both names are priced: a plan holds one of them per stage -- which one is the planner's per-stage policy -- and only the
+            # launches that exist in the measured step enter any sum)
+            for nm in fwd:
                 add(nm, (a_in + wts + a_out) * es + (a_out * 4 if name in ("head", "out") else 0), 2 * B * macs)
-            for nm in bwd[:1]:
+            for nm in bwd:
                 add(nm, (a_out + wts + 2 * a_in) * es, 2 * B * macs)
             add(wgr, (a_in + a_out) * es + wts * 4, 2 * B * macs)
         add("fwd_out_loss", B * (2 + 3) * int(na["n_z"]) * 4, 0)
