@@ -514,6 +514,35 @@ def test_lean_small_tile_kernel(V, monkeypatch, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("hidden", [(500, 500), (24, 24), (130, 70)])
+def test_fused_adam_launch_is_bitwise(V, monkeypatch, dtype, hidden):
+    """The small nets' weight-gradient launch with Adam in its epilogue (k_small_tn<.., ADAM>: interior tiles on whole 16-byte stores,
+    edge tiles with row bounds and a partial last quad (147 = 36 quads + 3), every XCD running its own list of layers) against (a)
+    the same launch on the plain tile order (AVAE_NO_XCD_PIECES=1) and (b) the unfused pair k_grouped + k_adam
+    (AVAE_NO_ADAM_FUSE=1): parameters, both moments and the last gradient bitwise after 4 steps -- the moments and the compute-dtype
+    shadows of step s are what step s+1 runs on, so a stale shadow column (a hipcc store-merging miscompile once produced one in
+    fp32) shows up from the second step on."""
+    archs = [make_arch("image", 784, hidden[0], hidden[1], 20), make_arch("joint", 147, max(8, hidden[0] // 2), max(8, hidden[1] // 2), 20)]
+    B = 64
+    rng = np.random.default_rng(5)
+    X = synth_batch(rng, 4 * B, [784, 147], [True, False])
+    res = []
+    for env in ({}, {"AVAE_NO_XCD_PIECES": "1"}, {"AVAE_NO_ADAM_FUSE": "1"}):
+        for k in ("AVAE_NO_XCD_PIECES", "AVAE_NO_ADAM_FUSE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct="relu", weights=[50, 1], assoc_lambda=8.0, batch_size=B,
+                                          compute_dtype=dtype, seed=1)
+        costs = [m.partial_fit([x[i * B:(i + 1) * B] for x in X]) for i in range(4)]
+        mo, vo, step = m.get_opt_state()
+        res.append((np.array(costs), m.get_params(), mo, vo, m.get_grads()))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B", [256, 100, 37])
 def test_chain2_experiment_is_bitwise(V, monkeypatch, dtype, B):
     """VERDICT r2 #6 (AVAE_CHAIN2=1): fwd_enc1 -> fwd_enc2 in ONE launch behind a row-block-local hand-off (write-through stores, a

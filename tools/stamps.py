@@ -22,7 +22,7 @@ def main():
     if os.path.exists(out):
         shutil.rmtree(out)
     shutil.copytree(os.path.join(ROOT, "vae_assoc_amd"), pkg, ignore=shutil.ignore_patterns("*.so", "__pycache__"))
-    src = [os.path.join(ROOT, "vae_assoc_amd", "csrc", f) for f in ("avae_kernels.hip", "avae_host.hip")]
+    src = [os.path.join(ROOT, "vae_assoc_amd", "csrc", f) for f in ("avae_kernels.hip", "avae_host.hip", "avae_comm.hip")]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DAVAE_STAMPS"] + os.environ.get("EXTRA_DEFS", "").split()
                    + src + ["-o", os.path.join(pkg, "libavae.so")], check=True)
     import torch
@@ -78,6 +78,12 @@ def main():
         if "AVAE_STAMPS_PRO" in os.environ.get("EXTRA_DEFS", "") and len(g):
             ep = "entry->item %.2f  item->addresses %.2f  addresses->loop %.2f" % (
                 (g[:, 6] - g[:, 0]).mean() / 100.0, (g[:, 7] - g[:, 6]).mean() / 100.0, (g[:, 1] - g[:, 7]).mean() / 100.0)
+        if os.environ.get("STAMPS_DETAIL") and os.environ["STAMPS_DETAIL"] in (names[l] if l < len(names) else ""):
+            base = t0.min()
+            q = [0, 10, 25, 50, 75, 90, 100]
+            for nm, col in (("entry", 0), ("loop start", 1), ("tile0 landed", 2), ("loop end", 3), ("end", 4)):
+                print("      %-13s percentiles %s us after the first block's entry: %s" % (
+                    nm, q, " ".join("%.2f" % ((np.percentile(g[:, col], x) - base) / 100.0) for x in q)))
         print("%-16s %6d %8.2f | %7.2f %7.2f %7.2f %7.2f | %8.2f  gap_before=%.2f  %s" % (
             names[l] if l < len(names) else "L%d" % l, live.sum(), span, seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4),
             (t0.max() - t0.min()) / 100.0, gap, ep))

@@ -154,6 +154,8 @@ struct TnItem {
     int ldw, ldt;
 };
 constexpr int kMaxTnItems = 32;
+constexpr int kTnPieces = 8;
+struct TnPiece { unsigned short item, tile_off, cum_end, pad; };      // tiles [tile_off, ...) of items[item]; cum_end = positions of the XCD up to and including this piece
 struct DevState;
 struct TnLaunchArgs {
     int n_items;
@@ -168,8 +170,15 @@ struct TnLaunchArgs {
     float beta1, beta2, eps;
     const DevState* st;      // lr_t of this step (published by the K_COST item earlier in the step)
     const ConvA* conv_tab;
+    // k_small_tn, XCD-owned pieces (xcd_pieces = 1): `items` holds WHOLE layers and XCD c runs the tiles of pieces[c][0..] in that
+    // order -- workgroup x (XCD x % 8, position x / 8 on it) serves the piece whose [previous cum_end, cum_end) holds its position.
+    // A layer's tiles then meet in ONE L2 (or two, where a layer is cut to balance the XCDs): its X / dA column panels come from
+    // HBM once instead of once per XCD (C2: 11.8 of the launch's 33.3 MB of reads were such re-reads).
+    int xcd_pieces;
+    TnPiece pieces[8][kTnPieces];
     TnItem items[kMaxTnItems];
 };
+static_assert(sizeof(TnLaunchArgs) <= 4096, "kernel arguments are passed by value: 4 KiB");
 
 struct DevState {
     long long step;          // number of applied Adam steps

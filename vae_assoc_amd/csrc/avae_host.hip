@@ -1127,6 +1127,65 @@ Launch finish_launch(avae_handle* h, std::vector<WorkItem>& items, int first, in
 
 void dp_ranges(const avae_handle* h, int* n_buckets, std::vector<avae_handle::Range> (&out)[2]);
 
+// k_small_tn: hand every XCD its own list of (layer, tile range) -- TnLaunchArgs::pieces.  The launch's entries (layers cut into
+// slices for the grid's sake) are merged back into whole layers; the layers, longest first, go whole to the fullest XCD that still
+// has room under the quota of ceil(tiles / 8) (best fit), and a layer that fits nowhere is cut: the emptiest XCD is filled up and
+// the rest tried again.  Leaves the launch as it was when an XCD would need more than kTnPieces pieces.
+void xcd_pieces(Launch& L) {
+    TnLaunchArgs& a = L.targs;
+    std::vector<TnItem> layers;
+    for (int i = 0; i < a.n_items; ++i) {
+        const TnItem& e = a.items[i];
+        if (e.tile_cnt <= 0) continue;
+        bool seen = false;
+        for (const TnItem& l : layers) seen = seen || l.out == e.out;
+        if (seen) continue;
+        TnItem l = e;
+        l.tile_off = 0; l.tile_cnt = e.tiles_m * e.tiles_n;
+        if (l.tile_cnt > 65535) return;
+        layers.push_back(l);
+    }
+    long total = 0;
+    for (const TnItem& l : layers) total += l.tile_cnt;
+    if (layers.empty() || total > 8L * 65535) return;
+    const int quota = (int)((total + 7) / 8);
+    std::vector<int> order(layers.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return layers[x].tile_cnt > layers[y].tile_cnt; });
+    struct Bin { int load = 0; std::vector<TnPiece> pc; };
+    Bin bins[8];
+    for (int li : order) {
+        int off = 0, left = layers[li].tile_cnt;
+        while (left > 0) {
+            int best = -1;
+            for (int b = 0; b < 8; ++b)          // whole (what is left of it): the fullest XCD it fits
+                if ((int)bins[b].pc.size() < kTnPieces && bins[b].load + left <= quota && (best < 0 || bins[b].load > bins[best].load)) best = b;
+            int take = left;
+            if (best < 0) {                      // cut: fill the emptiest XCD
+                for (int b = 0; b < 8; ++b)
+                    if ((int)bins[b].pc.size() < kTnPieces && bins[b].load < quota && (best < 0 || bins[b].load < bins[best].load)) best = b;
+                if (best < 0) return;
+                take = std::min(left, quota - bins[best].load);
+            }
+            bins[best].load += take;
+            bins[best].pc.push_back(TnPiece{(unsigned short)li, (unsigned short)off, (unsigned short)bins[best].load, 0});
+            off += take; left -= take;
+        }
+    }
+    int longest = 0;
+    for (int b = 0; b < 8; ++b) {
+        longest = std::max(longest, bins[b].load);
+        for (int i = 0; i < kTnPieces; ++i)
+            a.pieces[b][i] = i < (int)bins[b].pc.size() ? bins[b].pc[i] : TnPiece{0, 0, (unsigned short)bins[b].load, 0};
+    }
+    std::memset(a.items, 0, sizeof(a.items));
+    for (size_t i = 0; i < layers.size(); ++i) a.items[i] = layers[i];
+    a.n_items = (int)layers.size();
+    a.xcd_pieces = 1;
+    L.grid_x = 8 * longest; L.grid_y = 1; L.blocks = L.grid_x;
+    a.grid_x = L.grid_x;
+}
+
 void build_training_plan(avae_handle* h) {
     h->items.clear(); h->fwd.clear(); h->bwd.clear(); h->wgrad.clear(); h->conv_tab.clear();
     Builder bd(h, h->items, h->B, true);
@@ -1740,6 +1799,7 @@ void build_training_plan(avae_handle* h) {
             L.targs.d_v = h->at<float>(h->off_v) - h->grad();
             L.targs.beta1 = h->cfg.beta1; L.targs.beta2 = h->cfg.beta2; L.targs.eps = h->cfg.adam_eps;
             L.targs.st = h->state();
+            if (!std::getenv("AVAE_NO_XCD_PIECES")) xcd_pieces(L);
             h->wgrad_adam.push_back(L);
         }
     }

@@ -1917,10 +1917,23 @@ __global__ void __launch_bounds__(kThreads) k_small_tn(const TnLaunchArgs args, 
 #endif
     AVAE_STAMP(0)
     const int part = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const TnItem w = args.items[blockIdx.y];
+    int entry = blockIdx.y, t_piece = -1;
+    if (args.xcd_pieces) {       // XCD-owned pieces: this XCD's list of (layer, tile range); one more kernel-argument round trip than below
+        const TnPiece* row = args.pieces[part];
+        int e = 0, lo = 0;
+#pragma unroll
+        for (int i = 0; i < kTnPieces; ++i) { const int ce = row[i].cum_end; if (idx >= ce) { e = i + 1; lo = ce; } }
+        if (e >= kTnPieces) return;                                   // behind this XCD's last tile
+        entry = row[e].item; t_piece = row[e].tile_off + idx - lo;
+    }
+    const TnItem w = args.items[entry];
     asm volatile("" :: "s"(w.A), "s"(w.B), "s"(w.out), "s"(w.lda), "s"(w.ldb), "s"(w.K), "s"(w.ld0), "s"(w.tile_off));
+    float lr_t = 0.f;
+    if constexpr (ADAM) lr_t = args.st->lr_t;        // older than every tile: whatever load it becomes, the counted waits hold
     int t;
-    {
+    if (t_piece >= 0) {
+        t = t_piece;
+    } else {
         const int nt = w.tile_cnt;
         const int q = nt >> 3, r = nt & 7;
         if (idx >= q + (part < r ? 1 : 0)) return;
@@ -1954,6 +1967,23 @@ __global__ void __launch_bounds__(kThreads) k_small_tn(const TnLaunchArgs args, 
     AVAE_STAMP(1)
     const int npro = nk < RING - 1 ? nk : RING - 1;
     for (int p = 0; p < npro; ++p) AVAE_T_DMA(p, p)
+    // ADAM: this thread's theta / m / v of the block (4 rows x 16 bytes x 3 arrays), fetched in ONE burst at the top of the epilogue
+    // (clamped addresses: every lane loads something valid).  Fetching them beside the K loop instead (behind the prologue's tiles,
+    // counted in the loop's waits) was built and measured: no faster (C2: 12.4 us either way) -- the launch is paced by the bytes its
+    // epilogue moves, not by this round trip.
+    const int c4 = (tid & 15) * 4;
+    f32x4 pth[4], pmm[4], pvv[4];
+    auto fetch_state = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int grow = m0 + (tid >> 4) + 16 * k, gcol = n0 + c4;
+            const bool ok = grow < w.M && gcol < w.N;
+            const float* gp = w.out + (size_t)(ok ? grow : m0) * w.ld0 + (ok ? gcol : n0);
+            pth[k] = *reinterpret_cast<const f32x4*>(gp + args.d_theta);
+            pmm[k] = *reinterpret_cast<const f32x4*>(gp + args.d_m);
+            pvv[k] = *reinterpret_cast<const f32x4*>(gp + args.d_v);
+        }
+    };
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -2007,6 +2037,7 @@ __global__ void __launch_bounds__(kThreads) k_small_tn(const TnLaunchArgs args, 
         // accumulators -> an fp32 tile in LDS (the ring is free), then k_adam's tile body on it, W^T through the same tile.
         constexpr int LDT = 65;
         float* T = reinterpret_cast<float*>(smem);
+        fetch_state();                         // all twelve loads of the thread at once: ONE round trip (they used to be fetched per row group, behind the previous group's stores)
         lds_barrier();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -2015,40 +2046,68 @@ __global__ void __launch_bounds__(kThreads) k_small_tn(const TnLaunchArgs args, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) T[(wr * 32 + i * 16 + fr) * LDT + wc * 32 + j * 16 + 4 * fq + e] = acc[i][j][e];
         lds_barrier();
-        const float lr_t = args.st->lr_t, omb1 = 1.0f - args.beta1, omb2 = 1.0f - args.beta2;
-        const int c4 = (tid & 15) * 4;
+        const float omb1 = 1.0f - args.beta1, omb2 = 1.0f - args.beta2;
+        const int r4 = (tid & 15) * 4;                          // W^T: a lane takes four consecutive rows (m) of one column (n)
+        // The update itself runs for all four row groups of the thread BEFORE any store and outside any branch (clamped addresses
+        // made every fetched value a number): the wait for the twelve loads then sits in straight-line code.  Placed behind a
+        // row-validity branch it was repeated before every group -- as vmcnt(0), which on this ISA also waits for the previous
+        // group's stores to reach L2: four store round trips in a row.
+        float g[4][4], th[4][4], m[4][4], v[4][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = (tid >> 4) + 16 * k;
-            const int grow = m0 + r, gcol = n0 + c4;
-            if (grow < w.M && gcol < w.N) {
-                const int nv = w.N - gcol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g[k][e] = T[r * LDT + c4 + e]; th[k][e] = pth[k][e]; m[k][e] = pmm[k][e]; v[k][e] = pvv[k][e]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) adam_update(g[k][e], m[k][e], v[k][e], th[k][e], omb1, omb2, lr_t, args.eps);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[r * LDT + c4 + e] = th[k][e];
+        }
+        const bool full = m0 + BM <= w.M && n0 + BM <= w.N;     // a tile inside the layer (most of them): whole 16-byte stores, no bounds
+        auto store_group = [&](int k, float* gp, CT* wp) {
+            store4<float>(gp, g[k]);
+            store4<float>(gp + args.d_theta, th[k]); store4<float>(gp + args.d_m, m[k]); store4<float>(gp + args.d_v, v[k]);
+            store4<CT>(wp, th[k]);
+        };
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int grow = m0 + (tid >> 4) + 16 * k, gcol = n0 + c4;
+                store_group(k, w.out + (size_t)grow * w.ld0 + gcol, reinterpret_cast<CT*>(w.W) + (size_t)grow * w.ldw + gcol);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int grow = m0 + (tid >> 4) + 16 * k, gcol = n0 + c4;
                 float* gp = w.out + (size_t)grow * w.ld0 + gcol;
-                float g[4], th[4], m[4], v[4];
+                CT* wp = reinterpret_cast<CT*>(w.W) + (size_t)grow * w.ldw + gcol;
+                const int nv = w.N - gcol;
+                if (grow < w.M && nv >= 4) {
+                    store_group(k, gp, wp);
+                } else if (grow < w.M && nv > 0) {
+                    // a partial quad never touches the padding behind column N
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = T[r * LDT + c4 + e];
-                load4<float>(gp + args.d_theta, th); load4<float>(gp + args.d_m, m); load4<float>(gp + args.d_v, v);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) adam_update(g[e], m[e], v[e], th[e], omb1, omb2, lr_t, args.eps);
-                store_row<float>(gp, g, nv);
-                store_row<float>(gp + args.d_theta, th, nv); store_row<float>(gp + args.d_m, m, nv); store_row<float>(gp + args.d_v, v, nv);
-                store_row<CT>(reinterpret_cast<CT*>(w.W) + (size_t)grow * w.ldw + gcol, th, nv);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) T[r * LDT + c4 + e] = th[e];
+                    for (int e = 0; e < 3; ++e) if (e < nv) {
+                        gp[e] = g[k][e]; gp[args.d_theta + e] = th[k][e]; gp[args.d_m + e] = m[k][e]; gp[args.d_v + e] = v[k][e]; wp[e] = to_ct<CT>(th[k][e]);
+                    }
+                    // Keeps this arm's last store from being merged with the 16-byte stores of the other arm: hipcc (ROCm 7.2) sank
+                    // the two into one shared "fourth dword" store and left its value unset on the whole-quad lanes -- fp32
+                    // shadows came out with every fourth column stale (tools/adam_fuse_diag.py found it).
+                    asm volatile("; partial quad" ::: "memory");
+                }
             }
         }
         lds_barrier();
-        const int r4 = (tid & 15) * 4;                          // W^T: a lane takes four consecutive rows (m) of one column (n)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = (tid >> 4) + 16 * k;
             const int gcol = n0 + c, grow = m0 + r4;
-            if (gcol < w.N && grow < w.M) {
-                float v[4];
+            float t[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = T[(r4 + e) * LDT + c];
-                store_row<CT>(reinterpret_cast<CT*>(w.Wt) + (size_t)gcol * w.ldt + grow, v, w.M - grow);
-            }
+            for (int e = 0; e < 4; ++e) t[e] = T[(r4 + e) * LDT + c];
+            CT* tp = reinterpret_cast<CT*>(w.Wt) + (size_t)gcol * w.ldt + grow;
+            if (full) store4<CT>(tp, t);
+            else if (gcol < w.N && grow < w.M) store_row<CT>(tp, t, w.M - grow);
         }
     }
     AVAE_STAMP(4)
