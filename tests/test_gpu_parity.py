@@ -452,6 +452,19 @@ def test_conv_plan_is_implicit_gemm(V, monkeypatch):
     assert len(names) <= 24, (len(names), names)
 
 
+@pytest.mark.parametrize("nz", [33, 64])
+@pytest.mark.parametrize("policy", ["", "E:fwb,H:fwb,D1:fwb,DT:fwb"])
+def test_conv_branch_with_wide_latents(V, monkeypatch, nz, policy):
+    """2 n_z > 64: the head and latent-dgrad launches run on the 128-column tiles, which carry no implicit-GEMM gather; the planner
+    has to keep the conv heads' forward and the first decoder stage's latent gradient on their explicit routes there (it threw
+    "an implicit patch matrix on a tile configuration without the gather" -- found by tools/fuzz_parity.py conv)."""
+    if policy:
+        monkeypatch.setenv("AVAE_IMPL_POLICY", policy)
+    archs = [dict(make_arch("image", 784, 16, 64, nz), hidden_conv=True, n_hidden_gener_1=64, n_hidden_gener_2=16),
+             make_arch("joint", 147, 60, 40, nz)]
+    check_step_parity(V, archs, [True, False], [3.0, 1.0], 0.3, "relu", 17, "fp32", steps=2, drift_tol=2.5e-3)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_conv_only_model(V, dtype):
     """A single conv modality (no MLP modality at all, no association term)."""

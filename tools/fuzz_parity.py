@@ -4,7 +4,7 @@ dtype shadows and moments a step leaves behind only show in the next one), plus 
 (AVAE_NO_ADAM_FUSE=1, AVAE_NO_LEAN=1 ...) bitwise.  tests/test_gpu_parity.py::test_random_shapes is the fixed-seed subset that runs
 in the suite; this tool is for spending GPU minutes on shapes nobody thought of.
 
-    python tools/fuzz_parity.py [seconds] [seed]
+    python tools/fuzz_parity.py [seconds] [seed] [conv]
 """
 import os
 import sys
@@ -26,7 +26,51 @@ def main():
     rng = np.random.default_rng(seed)
     acts = ["relu", "softplus", "tanh", "sigmoid", "identity"]
     t0, case, bad = time.time(), 0, []
-    while time.time() - t0 < budget:
+    conv_mode = len(sys.argv) > 3 and sys.argv[3] == "conv"
+    while conv_mode and time.time() - t0 < budget:
+        # conv / deconv image branches (random depths, 1-3 modalities of which at least one is conv), THREE steps, fp32 and bf16, the
+        # default implicit-GEMM policy and every stage implicit / explicit -- each against the oracle (the routes sum in different
+        # orders: no bitwise twin here)
+        M = int(rng.integers(1, 4))
+        nz = int(rng.choice([int(x) for x in os.environ["FUZZ_NZ"].split(",")] if os.environ.get("FUZZ_NZ") else [2, 5, 8, 20, 33, 64]))
+        B = int(rng.choice([3, 8, 17, 32, 64]))
+        dtype = str(rng.choice(["fp32", "fp32", "bf16"]))
+        conv = [True] + [bool(rng.integers(0, 2)) for _ in range(M - 1)]
+        rng.shuffle(conv)
+        archs, binary, w = [], [], []
+        for m in range(M):
+            if conv[m]:
+                r1, r2 = int(rng.integers(1, 25)), int(rng.integers(1, 81))
+                g1, g2 = int(rng.choice([2, 6, 8, 16, 20, 64, 130, 160])), int(rng.integers(1, 21))
+                archs.append(dict(make_arch("c%d" % m, 784, r1, r2, nz), hidden_conv=True, n_hidden_gener_1=g1, n_hidden_gener_2=g2))
+                binary.append(True)
+            else:
+                archs.append(make_arch("m%d" % m, int(rng.integers(1, 200)), int(rng.integers(1, 90)), int(rng.integers(1, 90)), nz))
+                binary.append(bool(rng.integers(0, 2)))
+            w.append(float(rng.choice([0.5, 1.0, 3.0])))
+        lam = float(rng.choice([0.0, 0.3, 8.0]))
+        policy = str(rng.choice(["", "E:fwb,H:fwb,D1:fwb,DT:fwb", "none"]))
+        desc = "conv case %d seed %d: %s nz=%d B=%d policy=%r conv=%s archs=%s" % (case, seed, dtype, nz, B, policy, conv, [
+            (a.get("n_hidden_recog_1"), a.get("n_hidden_recog_2"), a.get("n_hidden_gener_1"), a.get("n_hidden_gener_2")) for a in archs])
+        try:
+            for k in ("AVAE_IMPL_POLICY", "AVAE_NO_IMPLICIT"):
+                os.environ.pop(k, None)
+            if policy == "none":
+                os.environ["AVAE_NO_IMPLICIT"] = "1"
+            elif policy:
+                os.environ["AVAE_IMPL_POLICY"] = policy
+            T.check_step_parity(V, archs, binary, w, lam, "relu", B, dtype, steps=3, seed=2000 + case, drift_tol=5e-3 if dtype == "fp32" else 2e-2)
+        except Exception as e:
+            msg = repr(e)
+            import re
+            nums = [float(x) for x in re.findall(r"(?<![\w.])(?:\d+\.\d+(?:e[-+]?\d+)?)", msg)] if "gradient mismatch" in msg else []
+            structural = not isinstance(e, AssertionError) or (nums and max(nums) > 0.2)
+            bad.append((desc, msg[:400], structural))
+            print("STRUCTURAL" if structural else "tolerance", desc, "\n     ", msg[:400], flush=True)
+        case += 1
+        if case % 5 == 0:
+            print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
+    while not conv_mode and time.time() - t0 < budget:
         M = int(rng.integers(1, 4))
         nz = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 20, 31, 32, 33, 48, 64]))
         B = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 100, 129, 200, 256, 300]))

@@ -436,6 +436,13 @@ void plan_memory(avae_handle* h) {
                     st.impl = geo && letters.find('f') != std::string::npos && (Cin * es) % 16 == 0;
                     st.impl_w = geo && (st.impl || letters.find('w') != std::string::npos) && (Cin * es) % 16 == 0;
                     st.impl_bwd = geo && letters.find('b') != std::string::npos && has_dgrad && (Cout * es) % 16 == 0;
+                    // Wide latents (2 n_z > 64): the head and latent-dgrad launches run on the 128-column tiles, which carry no
+                    // gather -- the heads' forward and the first decoder stage's latent gradient stay on their explicit routes there
+                    // (tools/fuzz_parity.py found the planner throwing for n_z = 33 with a conv modality).
+                    if (2 * h->nz > 64) {
+                        if (cls == "H") st.impl = false;
+                        if (cls == "D1") st.impl_bwd = false;
+                    }
                 }
                 if (plain_out) {     // hidden conv stage: own output / gradient buffers
                     // (the direct stage's one-channel maps are read and written pixel by pixel: the LAST map (28x28), whose consumer
