@@ -4,7 +4,7 @@ dtype shadows and moments a step leaves behind only show in the next one), plus 
 (AVAE_NO_ADAM_FUSE=1, AVAE_NO_LEAN=1 ...) bitwise.  tests/test_gpu_parity.py::test_random_shapes is the fixed-seed subset that runs
 in the suite; this tool is for spending GPU minutes on shapes nobody thought of.
 
-    python tools/fuzz_parity.py [seconds] [seed] [conv]
+    python tools/fuzz_parity.py [seconds] [seed] [conv | api]
 """
 import os
 import sys
@@ -26,6 +26,94 @@ def main():
     rng = np.random.default_rng(seed)
     acts = ["relu", "softplus", "tanh", "sigmoid", "identity"]
     t0, case, bad = time.time(), 0, []
+    api_mode = len(sys.argv) > 3 and sys.argv[3] == "api"
+    while api_mode and time.time() - t0 < budget:
+        # the rest of the surface on random models (MLP and conv modalities): transform / generate / reconstruct at row counts
+        # around batch_size against the oracle; a multi-step run against the same steps one by one, bitwise; save -> restore ->
+        # the next steps identical
+        import tempfile
+        import torch
+        from oracle import vae_assoc_oracle as O
+        M = int(rng.integers(1, 4))
+        nz = int(rng.choice([1, 2, 5, 8, 20, 32, 33, 64]))
+        B = int(rng.choice([1, 3, 8, 17, 32, 64, 100, 160]))
+        dtype = str(rng.choice(["fp32", "bf16"]))
+        archs, binary, w = [], [], []
+        for m in range(M):
+            if rng.integers(0, 4) == 0 and B <= 64:
+                g1, g2 = int(rng.choice([2, 8, 16, 64])), int(rng.integers(1, 21))
+                archs.append(dict(make_arch("c%d" % m, 784, int(rng.integers(1, 25)), int(rng.integers(1, 81)), nz), hidden_conv=True,
+                                  n_hidden_gener_1=g1, n_hidden_gener_2=g2))
+                binary.append(True)
+            else:
+                hs = [int(rng.integers(1, 301)) for _ in range(int(rng.integers(1, 4)))]
+                archs.append(make_arch("m%d" % m, int(rng.integers(1, 801)), 0, 0, nz, n_hidden=hs))
+                binary.append(bool(rng.integers(0, 2)))
+            w.append(float(rng.choice([0.5, 1.0, 50.0])))
+        lam = float(rng.choice([0.0, 0.3, 8.0]))
+        act = acts[case % len(acts)] if not any(a.get("hidden_conv") for a in archs) else "relu"
+        widths = [a["n_input"] for a in archs]
+        desc = "api case %d seed %d: %s M=%d nz=%d B=%d act=%s archs=%s binary=%s" % (case, seed, dtype, M, nz, B, act, [
+            (a["n_input"], a.get("n_hidden") or (a.get("n_hidden_recog_1"), a.get("n_hidden_recog_2"), a.get("n_hidden_gener_1"), a.get("n_hidden_gener_2")))
+            for a in archs], binary)
+        try:
+            model, ref = T.build_pair(V, archs, binary, w, lam, act, B, dtype, seed=3000 + case)
+            emu = ref if dtype == "fp32" else O.OracleAssocVAE(archs, binary, act, w, lam, 1e-3, B, params_flat=model.get_params().astype(np.float64), quant="bf16")
+            tol = 1e-5 if dtype == "fp32" else 4e-3
+            for rows in sorted(set([1, max(1, B - 1), B, B + 1, 2 * B + 5, int(rng.integers(1, 3 * B + 2))])):
+                X = synth_batch(rng, rows, widths, binary)
+                mus, rmu = model.transform(X), emu.transform(X)
+                z = rng.standard_normal((rows, nz)).astype(np.float32)
+                gen, rgen = model.generate(z), emu.generate(z)
+                e = [rng.standard_normal((rows, nz)).astype(np.float32) for _ in range(M)]
+                rec, rrec = model.reconstruct(X, eps=e), emu.reconstruct(X, eps=e)
+                for m in range(M):
+                    for nm, a, b in (("transform", mus[m], rmu[m]), ("generate", gen[m], rgen[m]), ("reconstruct", rec[m], rrec[m])):
+                        err = float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max()))
+                        if a.shape != b.shape or not err <= tol:
+                            raise AssertionError("%s rows=%d modality %d: shape %s vs %s, rel err %.3e" % (nm, rows, m, a.shape, b.shape, err))
+            # multi-step runs == single steps, bitwise (device tensors, column slices of one matrix)
+            n = int(rng.choice([2, 5, 16, 17, 21, 41]))
+            data = np.concatenate(synth_batch(rng, n * B, widths, binary), axis=1)
+            dev = torch.as_tensor(data).cuda()
+            cols = np.cumsum([0] + widths)
+            Xd = [dev[:, cols[m]:cols[m + 1]] for m in range(M)]
+            p0 = model.get_params()
+            res = []
+            for many in (False, True):
+                mm = V.AssocVariationalAutoEncoder(archs, binary=binary, transfer_fct=act, weights=w, assoc_lambda=lam, batch_size=B,
+                                                   compute_dtype=dtype, seed=7)
+                mm.set_params(p0)
+                if many:
+                    mm.partial_fit_steps(Xd, n, return_cost=False)
+                else:
+                    for i in range(n):
+                        mm.partial_fit([x[i * B:(i + 1) * B] for x in Xd], return_cost=False)
+                res.append((mm.cost_history(n).copy(), mm.get_params(), mm))
+            if not (np.array_equal(res[0][0], res[1][0], equal_nan=True) and np.array_equal(res[0][1], res[1][1], equal_nan=True)):      # (an unbounded net may diverge: NaN on both sides is agreement)
+                raise AssertionError("default plan vs single steps: a run of %d steps differs (costs equal: %s, NaN costs %d / %d)" % (
+                    n, np.array_equal(res[0][0], res[1][0], equal_nan=True), int(np.isnan(res[0][0]).sum()), int(np.isnan(res[1][0]).sum())))
+            # save -> restore -> identical continuation
+            with tempfile.TemporaryDirectory() as td:
+                a = res[1][2]
+                a.save_model(os.path.join(td, "m.ckpt"))
+                b = V.AssocVariationalAutoEncoder(archs, binary=binary, transfer_fct=act, weights=w, assoc_lambda=lam, batch_size=B,
+                                                  compute_dtype=dtype, seed=99)
+                b.restore_model(folder=td)
+                Xb = [x[:B] for x in Xd]
+                eb = rng.standard_normal((B, nz)).astype(np.float32)          # explicit: the internal draw is keyed by the replica's seed
+                ca, cb = a.partial_fit(Xb, eb), b.partial_fit(Xb, eb)
+                if not (ca == cb or (np.isnan(ca) and np.isnan(cb))) or not np.array_equal(a.get_params(), b.get_params(), equal_nan=True):
+                    raise AssertionError("default plan vs restored replica: the step after restore differs (%r vs %r)" % (ca, cb))
+            del model, res, a, b, mm
+        except Exception as e:
+            msg = repr(e)
+            structural = not isinstance(e, AssertionError) or "default plan vs" in msg or "shape" in msg and "rel err" in msg and float(msg.split("rel err ")[1].split("'")[0].split('"')[0]) > 0.2
+            bad.append((desc, msg[:400], structural))
+            print("STRUCTURAL" if structural else "tolerance", desc, "\n     ", msg[:400], flush=True)
+        case += 1
+        if case % 5 == 0:
+            print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
     conv_mode = len(sys.argv) > 3 and sys.argv[3] == "conv"
     while conv_mode and time.time() - t0 < budget:
         # conv / deconv image branches (random depths, 1-3 modalities of which at least one is conv), THREE steps, fp32 and bf16, the
@@ -70,7 +158,7 @@ def main():
         case += 1
         if case % 5 == 0:
             print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
-    while not conv_mode and time.time() - t0 < budget:
+    while not conv_mode and not api_mode and time.time() - t0 < budget:
         M = int(rng.integers(1, 4))
         nz = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 20, 31, 32, 33, 48, 64]))
         B = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 100, 129, 200, 256, 300]))
