@@ -4,7 +4,7 @@ dtype shadows and moments a step leaves behind only show in the next one), plus 
 (AVAE_NO_ADAM_FUSE=1, AVAE_NO_LEAN=1 ...) bitwise.  tests/test_gpu_parity.py::test_random_shapes is the fixed-seed subset that runs
 in the suite; this tool is for spending GPU minutes on shapes nobody thought of.
 
-    python tools/fuzz_parity.py [seconds] [seed] [conv | api]
+    python tools/fuzz_parity.py [seconds] [seed] [conv | api | dp]
 """
 import os
 import sys
@@ -114,6 +114,85 @@ def main():
         case += 1
         if case % 5 == 0:
             print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
+    dp_mode = len(sys.argv) > 3 and sys.argv[3] == "dp"
+    while dp_mode and time.time() - t0 < budget:
+        # the data-parallel contract on random models: R replicas of B rows each (row_offset r*B, batch_global R*B) --
+        # their gradients and costs SUM to the single replica's at R*B rows, and after the same reduced gradient is applied the
+        # replicas are bitwise equal
+        import ctypes as C
+        import torch
+        from vae_assoc_amd import _capi
+        M = int(rng.integers(1, 4))
+        nz = int(rng.choice([1, 2, 5, 8, 20, 32, 33, 64]))
+        R = int(rng.choice([2, 3, 4, 8]))
+        B = int(rng.choice([1, 3, 8, 17, 32, 64, 100]))
+        dtype = str(rng.choice(["fp32", "bf16"]))
+        archs, binary, w = [], [], []
+        for m in range(M):
+            if rng.integers(0, 4) == 0 and R * B <= 128:
+                g1, g2 = int(rng.choice([2, 8, 16, 64])), int(rng.integers(1, 21))
+                archs.append(dict(make_arch("c%d" % m, 784, int(rng.integers(1, 25)), int(rng.integers(1, 81)), nz), hidden_conv=True,
+                                  n_hidden_gener_1=g1, n_hidden_gener_2=g2))
+                binary.append(True)
+            else:
+                hs = [int(rng.integers(1, 301)) for _ in range(int(rng.integers(1, 4)))]
+                archs.append(make_arch("m%d" % m, int(rng.integers(1, 801)), 0, 0, nz, n_hidden=hs))
+                binary.append(bool(rng.integers(0, 2)))
+            w.append(float(rng.choice([0.5, 1.0, 50.0])))
+        lam = float(rng.choice([0.0, 0.3, 8.0]))
+        act = str(rng.choice(["softplus", "tanh", "sigmoid", "relu"])) if not any(a.get("hidden_conv") for a in archs) else "relu"
+        widths = [a["n_input"] for a in archs]
+        desc = "dp case %d seed %d: %s R=%d B=%d M=%d nz=%d act=%s archs=%s binary=%s" % (case, seed, dtype, R, B, M, nz, act, [
+            (a["n_input"], a.get("n_hidden") or (a.get("n_hidden_recog_1"), a.get("n_hidden_recog_2"), a.get("n_hidden_gener_1"), a.get("n_hidden_gener_2")))
+            for a in archs], binary)
+        try:
+            X = synth_batch(rng, R * B, widths, binary)
+            eps = rng.standard_normal((R * B, nz)).astype(np.float32)
+            kw = dict(binary=binary, transfer_fct=act, weights=w, assoc_lambda=lam, compute_dtype=dtype, seed=2)
+            full = V.AssocVariationalAutoEncoder(archs, batch_size=R * B, **kw)
+            p0 = full.get_params()
+            full._backward(X, eps)
+            g_full = full._grad_tensor().clone()
+            gsum = torch.zeros_like(g_full)
+            reps = []
+            for r in range(R):
+                rep = V.AssocVariationalAutoEncoder(archs, batch_size=B, **kw)
+                rep._L.avae_destroy(rep._h)
+                rep._cfg.row_offset, rep._cfg.batch_global = B * r, R * B
+                hnd = C.c_void_p()
+                _capi.check(None, rep._L.avae_create(C.byref(rep._cfg), C.byref(hnd)), "avae_create")
+                rep._h = hnd
+                rep.set_params(p0)
+                rep._backward([x[B * r:B * (r + 1)] for x in X], eps[B * r:B * (r + 1)])
+                if rep._grad_tensor().shape != g_full.shape:
+                    raise AssertionError("default plan vs shard: gradient buffers of different length")
+                gsum += rep._grad_tensor()
+                reps.append(rep)
+            torch.cuda.synchronize()
+            gf, gs = g_full.cpu().numpy().astype(np.float64), gsum.cpu().numpy().astype(np.float64)
+            if not abs(gf[-1] - gs[-1]) <= (1e-5 if dtype == "fp32" else 1e-4) * abs(gf[-1]):
+                raise AssertionError("cost: full %.6f vs sum of shards %.6f (rel err %.3e)" % (gf[-1], gs[-1], abs(gf[-1] - gs[-1]) / abs(gf[-1])))
+            err = float(np.abs(gf[:-1] - gs[:-1]).max() / max(np.abs(gf[:-1]).max(), 1e-30))
+            if not err <= (2e-5 if dtype == "fp32" else 2e-3):
+                raise AssertionError("gradient: full vs sum of shards, rel err %.3e" % err)
+            finals = []
+            for rep in reps:
+                rep._grad_tensor().copy_(gsum)
+                rep._apply(want_cost=False)
+                finals.append(rep.get_params())
+            for f in finals[1:]:
+                if not np.array_equal(finals[0], f):
+                    raise AssertionError("default plan vs peer replica: parameters differ after applying the same reduced gradient")
+            del full, reps
+        except Exception as e:
+            msg = repr(e)
+            big = "rel err" in msg and float(msg.split("rel err ")[1].rstrip("')\"")) > 0.05
+            structural = not isinstance(e, AssertionError) or "default plan vs" in msg or big
+            bad.append((desc, msg[:400], structural))
+            print("STRUCTURAL" if structural else "tolerance", desc, "\n     ", msg[:400], flush=True)
+        case += 1
+        if case % 5 == 0:
+            print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
     conv_mode = len(sys.argv) > 3 and sys.argv[3] == "conv"
     while conv_mode and time.time() - t0 < budget:
         # conv / deconv image branches (random depths, 1-3 modalities of which at least one is conv), THREE steps, fp32 and bf16, the
@@ -158,7 +237,7 @@ def main():
         case += 1
         if case % 5 == 0:
             print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
-    while not conv_mode and not api_mode and time.time() - t0 < budget:
+    while not conv_mode and not api_mode and not dp_mode and time.time() - t0 < budget:
         M = int(rng.integers(1, 4))
         nz = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 20, 31, 32, 33, 48, 64]))
         B = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 100, 129, 200, 256, 300]))
