@@ -172,10 +172,18 @@ def _vector_worker(rank, world, port, out_dir):
         from vae_assoc_amd.vae_assoc import AssocVariationalAutoEncoder
         L = _capi.lib()
         worst = {}
-        for wire in ("fp32", "bf16"):
-            for nb in (1, 2):
-                m = AssocVariationalAutoEncoder(ARCHS, batch_size=32, compute_dtype="bf16", device=0, data_parallel=True, comm="ipc", comm_buckets=nb,
-                                                wire_dtype=wire, **KW)
+        # C2's nets (6.13 MB), a net whose whole buffer is a few granules (most workgroups have an empty chunk of every shard and
+        # still have to signal), and three modalities of odd widths
+        shapes = {"c2": ARCHS,
+                  "tiny": [make_arch("a", 5, 3, 2, 1), make_arch("b", 3, 2, 2, 1)],
+                  "odd": [make_arch("a", 333, 0, 0, 7, n_hidden=[129, 65, 31]), make_arch("b", 17, 0, 0, 7, n_hidden=[9]), make_arch("c", 250, 0, 0, 7, n_hidden=[77, 200])]}
+        for shape, wire, nb in [(sh, wi, n) for sh in shapes for wi in ("fp32", "bf16") for n in (1, 2)]:
+            if True:
+                kw = dict(KW)
+                if len(shapes[shape]) != 2:
+                    kw.update(binary=[True, False, False], weights=[1.0, 1.0, 1.0])
+                m = AssocVariationalAutoEncoder(shapes[shape], batch_size=32, compute_dtype="bf16", device=0, data_parallel=True, comm="ipc", comm_buckets=nb,
+                                                wire_dtype=wire, **kw)
                 n_el = m._grad_view.numel()
                 srcs = [np.random.default_rng(100 + r).standard_normal(n_el).astype(np.float32) for r in range(world)]
                 want = np.sum([s.astype(np.float64) for s in srcs], axis=0)
@@ -191,8 +199,8 @@ def _vector_worker(rank, world, port, out_dir):
                     d = np.abs(got - want)
                     tol = 1e-6 if wire == "fp32" else 8e-3          # bf16: 2^-9 per term of the sum, once more on the rounded result
                     assert d[-1] <= 1e-6 * max(1.0, abs(want[-1])), "the cost slot always travels as fp32"
-                    assert d.max() <= tol * np.abs(want).max(), (world, wire, nb, rep, float(d.max()), int(np.argmax(d)))
-                    worst["%s_%d" % (wire, nb)] = got
+                    assert d.max() <= tol * np.abs(want).max(), (world, shape, wire, nb, rep, float(d.max()), int(np.argmax(d)))
+                    worst["%s_%s_%d" % (shape, wire, nb)] = got
                 del m
                 dist.barrier()
         np.savez(os.path.join(out_dir, "vec_r%d.npz" % rank), **worst)
