@@ -621,7 +621,8 @@ def test_tail_product_route(V, monkeypatch, dtype, B):
                                  {"AVAE_NO_IMPLICIT": "1", "AVAE_NO_WADJ_FOLD": "1"}, {"AVAE_NO_IMPLICIT": "1", "AVAE_NO_SUMS_MERGE": "1"},
                                  {"AVAE_IMPL_POLICY": "E:fwb,H:fwb,D1:fwb,DT:fwb"}, {"AVAE_IMPL_POLICY": "E:fw,H:fwb,D1:fwb,DT:b"},
                                  {"AVAE_IMPL_POLICY": "E:fw,H:fwb,D1:fwb,DT:wb"}, {"AVAE_IMPL_POLICY": "E:b,H:b,D1:b,DT:w"},
-                                 {"AVAE_IMPL_POLICY": "E:fwb,H:fwb,D1:fwb,DT:fwb", "AVAE_NO_THIN": "1"}])
+                                 {"AVAE_IMPL_POLICY": "E:fwb,H:fwb,D1:fwb,DT:fwb", "AVAE_NO_THIN": "1"},
+                                 {"AVAE_NO_THIN_FAST": "1"}, {"AVAE_THIN_FAST_SPLIT": "2,2,2"}, {"AVAE_THIN_FAST_SPLIT": "4,1,4"}])
 def test_planner_switches_conv_routes(V, monkeypatch, env):
     """Conv stages through the patch-matrix route instead of the direct / adjoint-frame ones; the MLP modality's hidden layers as
     launches of their own instead of riding in the conv modality's GEMM launches (AVAE_NO_SINK); the sums behind the weight

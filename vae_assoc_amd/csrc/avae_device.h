@@ -314,7 +314,15 @@ struct ThinSeg {
     int Kp;                  // roundup(k*k*Cin + 1, 4)
     int block_base;
     int img_y, img_dy;       // > 0: elements from one image's map to the next in Y / dY (dense rows); 0: OH*OW*ldy / OH*OW*lddy
+    int split;               // workgroups per image: kThinSplit, or 1 on the block-structured path below
+    int fast;                // the reference's geometry (k 5, stride-2 transposed conv in gather form: so 1, d 2, pad 3, OH = 2 IH, 8 or 16
+                             // input channels): one workgroup per image; forward = a thread per 2x2 output block over its 3x3 input
+                             // neighbourhood (every tap test folds at compile time), input gradient = a thread per (pixel, channel quad)
+                             // over the 5x5 window, filter gradient = a thread per (tap, tenth of the pixels) for all channels
 };
+inline bool thin_fast_geometry(const ConvGeom& g) {
+    return g.k == 5 && g.so == 1 && g.d == 2 && g.pad == 3 && g.OH == 2 * g.IH && g.OW == 2 * g.IW && (g.Cin == 8 || g.Cin == 16) && g.ones;
+}
 struct ThinArgs { ThinSeg seg[kMaxMod]; int n_seg; int mode; };
 void launch_thin(int compute_dtype, const ThinArgs& a, int n_blocks, hipStream_t s);
 void launch_colsum(const ReduceArgs& a, int n_blocks, hipStream_t s);

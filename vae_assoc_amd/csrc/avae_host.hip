@@ -331,6 +331,17 @@ void check_config(const avae_config& c) {
 }
 
 // Lays out the whole workspace; with h->ws == nullptr it only computes sizes.
+// workgroups per image of the direct one-channel stage: 1 on the block-structured path (the reference's geometry), else kThinSplit
+inline bool thin_fast(const ConvGeom& g) { return thin_fast_geometry(g) && !std::getenv("AVAE_NO_THIN_FAST"); }
+// workgroups per image of the direct one-channel stage in mode 0 / 1 / 2 (AVAE_THIN_FAST_SPLIT="a,b,c": A/B runs)
+inline int thin_split(const ConvGeom& g, int mode) {
+    if (!thin_fast(g)) return kThinSplit;
+    int sp[3] = {1, 4, 1};       // measured on c2conv (tools/thin_split_ab.sh): forward 7.1 us at 1 (12.3 at 2, 21.6 at 4), dX 10.4 / 7.6 / 5.8, dF 8.3 / 8.1 / 10.5
+    if (const char* e = std::getenv("AVAE_THIN_FAST_SPLIT")) std::sscanf(e, "%d,%d,%d", &sp[0], &sp[1], &sp[2]);
+    const int v = sp[mode];
+    return v == 1 || v == 2 || v == 4 ? v : 1;
+}
+
 void plan_memory(avae_handle* h) {
     const avae_config& c = h->cfg;
     h->es = c.compute_dtype == AVAE_BF16 ? 2 : 4;
@@ -504,7 +515,7 @@ void plan_memory(avae_handle* h) {
                 if (thin) {
                     st.thin = true;
                     st.thin_kp = (int)rup(K + 1, 4);
-                    st.thin_blocks = B * kThinSplit;      // filter-gradient partial sums: one slice per workgroup
+                    st.thin_blocks = B * thin_split(st.g, 2);      // filter-gradient partial sums: one slice per workgroup
                     st.thin_part = b.take((size_t)st.thin_blocks * st.thin_kp * 4);
                 }
                 pflat += (size_t)k * k * Cin_in * Cout + (flat == 0 ? 0 : Cout);
@@ -786,6 +797,7 @@ struct Builder {
         t.act = st.act; t.act_in = prev.act;
         t.dY = p<void>(st.dY.rm); t.lddy = st.dY.ld;
         if (st.dense_map) { t.img_y = st.Y.ld; t.ldy = 1; t.img_dy = st.dY.ld; t.lddy = 1; }      // dense rows: pixel stride 1, image stride = row stride
+        t.split = thin_split(st.g, 0); t.fast = thin_fast(st.g) ? 1 : 0;      // (the training launches set the split of their mode: thin_launch)
         t.dX = p<void>(prev.dY.rm); t.lddx = prev.dY.ld;
         t.part = p<float>(st.thin_part); t.Kp = st.thin_kp;
         return t;
@@ -1296,8 +1308,9 @@ void build_training_plan(avae_handle* h) {
         int base = 0;
         for (Mod& md : h->mods) if (md.conv && md.cdec[i].thin) {
             ThinSeg t = bd.thin_seg(md.cdec[i], md.cdec[i - 1]);
+            t.split = thin_split(md.cdec[i].g, mode);
             t.block_base = base;
-            base += h->B * kThinSplit;                     // kThinSplit workgroups per image in every mode
+            base += h->B * t.split;                        // workgroups per image
             L.ta.seg[L.ta.n_seg++] = t;
         }
         L.blocks = base;
@@ -1940,7 +1953,7 @@ void build_inference(avae_handle* h, int m, bool enc, int rows) {
                 ThinSeg t = bd.thin_seg(md.cdec[i], md.cdec[i - 1]);
                 t.block_base = 0;
                 L.ta.seg[0] = t; L.ta.n_seg = 1;
-                L.blocks = rows * kThinSplit;
+                L.blocks = rows * t.split;
                 inf.launches.push_back(L);
                 continue;
             }

@@ -2792,6 +2792,172 @@ __device__ __forceinline__ int mod_small(int n, int q) {
     return r < 0 ? r + q : r;
 }
 
+// The reference's last decoder stage (5x5 transposed conv, stride 2, TF-SAME crop 1 / 2, 14x14xCin -> 28x28x1; gather form: ih =
+// (oh + kh - 3) / 2), block-structured, ONE workgroup per image (ThinSeg::fast): the generic loops below spend most of their
+// instructions on tap arithmetic and, split four ways, stage every image four times.
+//   forward   output block (2i + dh, 2j + dw), dh, dw in {0, 1}, reads input pixels (i - 1 + a, j - 1 + b), a, b in {0, 1, 2}, through
+//             tap kh = 2a + 1 - dh (kw alike) where that is < 5: 25 (pixel, output) pairs per block, known at compile time
+//   dX        input pixel (ih, iw) collects dY[2 ih + 3 - kh][2 iw + 3 - kw] F[kh][kw][c] over the 5x5 taps (same order as the generic loop)
+//   dF        thread (tap, s) adds X[p][:] dY[...] over pixels p = s, s + 10, ...; the ten partial sums of a tap are added in order
+template <typename CT, int CQ, int MODE>
+__device__ __forceinline__ void thin_fast_body(const ThinSeg& w, const ConvGeom& g, int b, int sub, int bid, const CT* X,
+                                               float* sx, const float* sf, const float* sdy, float* sred) {
+    constexpr int mode = MODE;
+    constexpr int Cin = 4 * CQ, K = 25 * Cin, S = 10;
+    const int tid = threadIdx.x, IH = g.IH, IW = g.IW, OH = g.OH, OW = g.OW, npi = IH * IW, npo = OH * OW;
+    if constexpr (mode == 0) {
+        CT* Y = reinterpret_cast<CT*>(w.Y) + (size_t)b * (w.img_y > 0 ? w.img_y : npo * w.ldy);
+        const float bias = sf[K];
+        const int per = (npi + w.split - 1) / w.split, blk_end = min(npi, (sub + 1) * per);
+        for (int blk = sub * per + tid; blk < blk_end; blk += kThreads) {
+            const int i0 = blk / IW, j0 = blk - i0 * IW;
+            float acc[4] = {bias, bias, bias, bias};
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa) {
+                const int ih = i0 - 1 + aa;
+                if (ih < 0 || ih >= IH) continue;
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) {
+                    const int iw = j0 - 1 + bb;
+                    if (iw < 0 || iw >= IW) continue;
+                    const float* xr = sx + (ih * IW + iw) * Cin;
+#pragma unroll
+                    for (int cq = 0; cq < CQ; ++cq) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(xr + 4 * cq);
+#pragma unroll
+                        for (int dh = 0; dh < 2; ++dh) {
+                            const int kh = 2 * aa + 1 - dh;
+                            if (kh >= 5) continue;
+#pragma unroll
+                            for (int dw = 0; dw < 2; ++dw) {
+                                const int kw = 2 * bb + 1 - dw;
+                                if (kw >= 5) continue;
+                                const f32x4 f = *reinterpret_cast<const f32x4*>(sf + (kh * 5 + kw) * Cin + 4 * cq);
+                                float& o = acc[dh * 2 + dw];
+                                o += x[0] * f[0]; o += x[1] * f[1]; o += x[2] * f[2]; o += x[3] * f[3];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 2; ++dw)
+                    Y[(size_t)((2 * i0 + dh) * OW + 2 * j0 + dw) * w.ldy] = (CT)act_fwd(w.act, acc[dh * 2 + dw]);
+        }
+    } else if constexpr (mode == 1) {
+        CT* dX = reinterpret_cast<CT*>(w.dX) + (size_t)b * npi * w.lddx;
+        const int per = (npi * CQ + w.split - 1) / w.split, idx_end = min(npi * CQ, (sub + 1) * per);
+        for (int idx = sub * per + tid; idx < idx_end; idx += kThreads) {
+            const int pix = idx / CQ, c0 = (idx - pix * CQ) * 4;
+            const int ih = pix / IW, iw = pix - ih * IW;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 5; ++kh) {
+                const int oh = 2 * ih + 3 - kh;
+                if ((unsigned)oh >= (unsigned)OH) continue;
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) {
+                    const int ow = 2 * iw + 3 - kw;
+                    if ((unsigned)ow >= (unsigned)OW) continue;
+                    const float dy = sdy[oh * OW + ow];
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(sf + (kh * 5 + kw) * Cin + c0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += dy * f[e];
+                }
+            }
+            float xv[4];
+            load4<CT>(X + (size_t)pix * g.src_sp + c0, xv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] *= act_bwd(w.act_in, xv[e]);
+            store4<CT>(dX + (size_t)pix * w.lddx + c0, acc);
+        }
+    } else {
+        if (tid < 64) {                                     // bias gradient: this workgroup's share of the map's sum, 64 strided partial sums added in order below
+            const int per = (npo + w.split - 1) / w.split, e = min(npo, (sub + 1) * per);
+            float sacc = 0.0f;
+            for (int i = sub * per + tid; i < e; i += 64) sacc += sdy[i];
+            sred[tid] = sacc;
+        }
+        const int pper = (npi + w.split - 1) / w.split, p_end = min(npi, (sub + 1) * pper);      // this workgroup's share of the input pixels
+        const int tap = tid / S, s = tid - tap * S;
+        f32x4 acc[CQ];
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) acc[cq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tap < 25) {
+            const int kh = tap / 5, kw = tap - kh * 5;
+            for (int p = sub * pper + s; p < p_end; p += S) {
+                const int ih = p / IW, iw = p - ih * IW;
+                const int oh = 2 * ih + 3 - kh, ow = 2 * iw + 3 - kw;
+                if ((unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW) {
+                    const float dy = sdy[oh * OW + ow];
+#pragma unroll
+                    for (int cq = 0; cq < CQ; ++cq) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(sx + p * Cin + 4 * cq);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[cq][e] += dy * x[e];
+                    }
+                }
+            }
+        }
+        lds_barrier();                                       // every read of the staged image is done: its space takes the partial sums
+        if (tap < 25) {
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) *reinterpret_cast<f32x4*>(sx + (tap * S + s) * Cin + 4 * cq) = acc[cq];
+        }
+        lds_barrier();
+        for (int t = tid; t < w.Kp; t += kThreads) {
+            float v = 0.0f;
+            if (t < K) {
+                const int tp = t / Cin, c = t - tp * Cin;
+#pragma unroll
+                for (int q = 0; q < S; ++q) v += sx[(tp * S + q) * Cin + c];
+            } else if (t == K) {
+                for (int i = 0; i < 64; ++i) v += sred[i];
+            }
+            w.part[(size_t)(bid - w.block_base) * w.Kp + t] = v;
+        }
+    }
+}
+
+// ... as kernels of their own (one per mode and channel count: each gets the registers its loops need, and the generic kernel below
+// keeps its occupancy).  Every segment of the launch is on this path (host: launch_thin).
+template <typename CT, int CQ, int MODE>
+__global__ void __launch_bounds__(kThreads) k_thin_fast(ThinArgs a) {
+    __shared__ __attribute__((aligned(16))) float sx[kThinIn];
+    __shared__ __attribute__((aligned(16))) float sf[kThinF + 4];
+    __shared__ float sdy[kThinOut];
+    __shared__ float sred[64];
+    constexpr int Cin = 4 * CQ;
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    int it = 0;
+    for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
+    const ThinSeg& w = a.seg[it];
+    const ConvGeom g = w.g;
+    const int b = (bid - w.block_base) / w.split, sub = (bid - w.block_base) % w.split;      // image, share of its work
+    const CT* X = reinterpret_cast<const CT*>(w.X) + (size_t)b * g.src_sb;
+    const int npi = g.IH * g.IW, npo = g.OH * g.OW;
+    if constexpr (MODE != 1) {                            // input planes
+        for (int i = tid; i < npi * CQ; i += kThreads) {
+            const int px = i / CQ, c = (i - px * CQ) * 4;
+            float v[4];
+            load4<CT>(X + (size_t)px * g.src_sp + c, v);
+            *reinterpret_cast<f32x4*>(sx + px * Cin + c) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+    if constexpr (MODE != 2) {                            // filter taps + bias
+        const CT* F = reinterpret_cast<const CT*>(w.Wt);
+        for (int i = tid; i < 25 * Cin + 1; i += kThreads) sf[i] = ct_load<CT>(F + i);
+    }
+    if constexpr (MODE != 0) {                            // output-gradient map
+        const CT* dY = reinterpret_cast<const CT*>(w.dY) + (size_t)b * (w.img_dy > 0 ? w.img_dy : npo * w.lddy);
+        for (int i = tid; i < npo; i += kThreads) sdy[i] = ct_load<CT>(dY + (size_t)i * w.lddy);
+    }
+    lds_barrier();
+    thin_fast_body<CT, CQ, MODE>(w, g, b, sub, bid, X, sx, sf, sdy, sred);
+}
+
 // One workgroup per image in every mode: the image's input planes (IH*IW*Cin <= kThinIn), its output(-gradient) map
 // (OH*OW <= kThinOut) and the filter (Kp <= kThinF) sit in LDS as fp32; products and sums are fp32 (operands were rounded to
 // the compute type when they were stored, as on the GEMM path).
@@ -2806,7 +2972,7 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
     for (int i = 1; i < a.n_seg; ++i) if (bid >= a.seg[i].block_base) it = i;
     const ThinSeg& w = a.seg[it];
     const ConvGeom g = w.g;
-    const int b = (bid - w.block_base) / kThinSplit, sub = (bid - w.block_base) % kThinSplit;     // image, share of its outputs
+    const int b = (bid - w.block_base) / w.split, sub = (bid - w.block_base) % w.split;     // image, share of its outputs (fast path: one workgroup per image)
     const CT* X = reinterpret_cast<const CT*>(w.X) + (size_t)b * g.src_sb;
     const CT* F = reinterpret_cast<const CT*>(w.Wt);
     const int K = g.k * g.k * g.Cin, Cin = g.Cin;
@@ -2838,8 +3004,8 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
     if (a.mode == 0) {
         // Y[oh, ow] = act(bias + sum over taps (kh, kw) with ih = (oh*so + kh - pad)/d an integer in [0, IH) (same for w))
         CT* Y = reinterpret_cast<CT*>(w.Y) + (size_t)b * (w.img_y > 0 ? w.img_y : npo * w.ldy);
-        const int p_end = min(npo, (sub + 1) * ((npo + kThinSplit - 1) / kThinSplit));
-        for (int p = sub * ((npo + kThinSplit - 1) / kThinSplit) + tid; p < p_end; p += kThreads) {
+        const int p_end = min(npo, (sub + 1) * ((npo + w.split - 1) / w.split));
+        for (int p = sub * ((npo + w.split - 1) / w.split) + tid; p < p_end; p += kThreads) {
             const int oh = p / g.OW, ow = p - oh * g.OW;
             const int bh = oh * g.so - g.pad, bw = ow * g.so - g.pad;
             int kh0 = max(0, -bh), kw0 = max(0, -bw);
@@ -2866,7 +3032,7 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
         // dX[ih, iw, c] = act_in'(X) * sum over taps with oh = (ih*d + pad - kh)/so an integer in [0, OH) of dY[oh, ow] * F[kh, kw, c]
         const int Q = (Cin + 3) >> 2;
         CT* dX = reinterpret_cast<CT*>(w.dX) + (size_t)b * npi * w.lddx;
-        const int per = (npi * Q + kThinSplit - 1) / kThinSplit, i_end = min(npi * Q, (sub + 1) * per);
+        const int per = (npi * Q + w.split - 1) / w.split, i_end = min(npi * Q, (sub + 1) * per);
         for (int idx = sub * per + tid; idx < i_end; idx += kThreads) {
             const int pix = idx / Q, c0 = (idx - pix * Q) * 4;
             const int ih = pix / g.IW, iw = pix - ih * g.IW;
@@ -2897,7 +3063,7 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
         // t + 256, ...); part[image][K] = bias gradient = sum of the map
         {   // bias: 64 strided partial sums, then thread 0 adds them in order
             if (tid < 64) {                                     // this workgroup's share of the map
-                const int per = (npo + kThinSplit - 1) / kThinSplit, e = min(npo, (sub + 1) * per);
+                const int per = (npo + w.split - 1) / w.split, e = min(npo, (sub + 1) * per);
                 float sacc = 0.0f;
                 for (int i = sub * per + tid; i < e; i += 64) sacc += sdy[i];
                 sred[tid] = sacc;
@@ -2908,7 +3074,7 @@ __global__ void __launch_bounds__(kThreads) k_thin(ThinArgs a) {
             float acc = 0.0f;
             if (t < K) {
                 const int kp = t / Cin, c = t - kp * Cin, kh = kp / g.k, kw = kp - kh * g.k;
-                const int hper = (g.IH + kThinSplit - 1) / kThinSplit;      // this workgroup's share of the input rows
+                const int hper = (g.IH + w.split - 1) / w.split;      // this workgroup's share of the input rows
                 for (int ih = sub * hper; ih < min(g.IH, (sub + 1) * hper); ++ih) {
                     bool okh;
                     const int oh = div_small(ih * g.d + g.pad - kh, g.so, okh);
@@ -2975,8 +3141,21 @@ void launch_colsum(const ReduceArgs& a, int n_blocks, hipStream_t s) {
     AVAE_LAUNCH(k_colsum, dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
 
+template <typename CT, int CQ> static void launch_thin_fast(const ThinArgs& a, int n_blocks, hipStream_t s) {
+    if (a.mode == 0) AVAE_LAUNCH((k_thin_fast<CT, CQ, 0>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else if (a.mode == 1) AVAE_LAUNCH((k_thin_fast<CT, CQ, 1>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+    else AVAE_LAUNCH((k_thin_fast<CT, CQ, 2>), dim3(n_blocks), dim3(kThreads), 0, s, a);
+}
 void launch_thin(int compute_dtype, const ThinArgs& a, int n_blocks, hipStream_t s) {
     if (n_blocks <= 0) return;
+    bool fast = a.n_seg > 0;
+    for (int i = 0; i < a.n_seg; ++i) fast = fast && a.seg[i].fast && a.seg[i].g.Cin == a.seg[0].g.Cin;
+    if (fast) {
+        const bool c16 = a.seg[0].g.Cin == 16;
+        if (compute_dtype == AVAE_BF16) { if (c16) launch_thin_fast<__bf16, 4>(a, n_blocks, s); else launch_thin_fast<__bf16, 2>(a, n_blocks, s); }
+        else { if (c16) launch_thin_fast<float, 4>(a, n_blocks, s); else launch_thin_fast<float, 2>(a, n_blocks, s); }
+        return;
+    }
     if (compute_dtype == AVAE_BF16) AVAE_LAUNCH((k_thin<__bf16>), dim3(n_blocks), dim3(kThreads), 0, s, a);
     else AVAE_LAUNCH((k_thin<float>), dim3(n_blocks), dim3(kThreads), 0, s, a);
 }
