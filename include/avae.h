@@ -204,7 +204,9 @@ int avae_timing_report(avae_handle* h, char* buf, size_t buf_bytes);
  * on the library's comm stream inside the step).  Every rank must make the same sequence of calls. */
 int avae_comm_allreduce(avae_handle* h, int32_t bucket, void* stream);
 /* Copies a named internal tensor to the host as fp32 (tests): "mulv<m>" [batch,2*n_z], "eps" [batch,n_z], "E<m>_<k>" / "D<m>_<k>" the
- * stored output of encoder / decoder hidden layer k of modality m [batch, width] (the last forward pass's relu decisions). */
+ * stored output of encoder / decoder hidden layer k of modality m [batch, width] (the last forward pass's relu decisions);
+ * "shadow_err" -> {max |W - theta|, max |W^T - theta|, layers checked, worst layer}: the compute-dtype weight shadows against the
+ * parameters rounded once (must be 0, 0 after any call). */
 int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t max_floats, size_t* n_floats);
 
 #ifdef __cplusplus

@@ -72,3 +72,15 @@ def concat_masks(parts):
     """row-wise concatenation of hip_relu_masks of several shards"""
     return [{key: [np.concatenate([p[m][key][k] for p in parts]) for k in range(len(parts[0][m][key]))] for key in ("enc", "dec")}
             for m in range(len(parts[0]))]
+
+
+def shadow_err(model):
+    """(max |W - theta|, max |W^T - theta|, layers checked) over every dense layer and conv stage (avae_debug_fetch "shadow_err"): the
+    compute-dtype shadows the optimiser rewrites must BE the parameters, rounded once.  A stale shadow entry would only show in the
+    next step's arithmetic; this sees it at once."""
+    import ctypes as C
+    buf = np.zeros(4, np.float32)
+    cnt = C.c_size_t(0)
+    rc = model._L.avae_debug_fetch(model._h, b"shadow_err", buf.ctypes.data_as(C.c_void_p), 4, C.byref(cnt))
+    assert rc == 0 and cnt.value == 4, model._L.avae_last_error(model._h)
+    return float(buf[0]), float(buf[1]), int(buf[2])

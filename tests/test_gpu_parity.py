@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, hip_relu_masks, make_arch, synth_batch
+from conftest import GOLDEN, hip_relu_masks, make_arch, synth_batch, shadow_err
 from oracle import vae_assoc_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -123,6 +123,7 @@ def check_step_parity(V, archs, binary, weights, lam, act, B, dtype, steps=3, se
     # Adam normalises the step: an element with |g| ~ 1e-8 turns a 1e-7 relative gradient error into
     # a visible fraction of lr, so the end-to-end drift bound is loose; the arithmetic was checked above
     assert dp <= (drift_tol if drift_tol is not None else 2e-4 if fp32 else 2.5 * steps * lr), "params drift %.3e" % dp
+    assert shadow_err(model)[:2] == (0.0, 0.0), "a compute-dtype shadow differs from its parameters"
     return model, emu, X, eps
 
 
@@ -549,6 +550,7 @@ def test_fused_adam_launch_is_bitwise(V, monkeypatch, dtype, hidden):
                                           compute_dtype=dtype, seed=1)
         costs = [m.partial_fit([x[i * B:(i + 1) * B] for x in X]) for i in range(4)]
         mo, vo, step = m.get_opt_state()
+        assert shadow_err(m)[:2] == (0.0, 0.0), env
         res.append((np.array(costs), m.get_params(), mo, vo, m.get_grads()))
     for other in res[1:]:
         for a, b in zip(res[0], other):
@@ -1152,6 +1154,7 @@ def test_determinism_and_stress_config_c4(V):
         m = V.AssocVariationalAutoEncoder(archs, batch_size=B, **kw)
         assert m.n_params == 14900387
         costs = [m.partial_fit(X, eps) for _ in range(5)]
+        assert shadow_err(m) == (0.0, 0.0, 20)                          # both compute-dtype shadows of all 20 layers = the parameters, rounded once
         runs.append((costs, m.get_params()))
     assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
     costs = runs[0][0]

@@ -3336,6 +3336,56 @@ int avae_debug_fetch(avae_handle* h, const char* name, float* host_dst, size_t m
             if (n_floats) *n_floats = cnt;
             return;
         }
+        else if (n == "shadow_err") {
+            // tests: the compute-dtype shadows the optimiser rewrites must BE the parameters (rounded once): W[r][c] and W^T[c][r]
+            // against theta[r][c] for every dense layer and conv stage -> {max |W - theta|, max |W^T - theta|, layers checked, worst layer}.
+            // A stale or misplaced shadow entry only shows in the NEXT step's arithmetic; this sees it at once, on any configuration.
+            if (max_floats < 4) throw Err("debug_fetch: destination too small");
+            HIP_OK(hipDeviceSynchronize());
+            auto round_ct = [&](float v) {
+                if (h->es == 4) return v;
+                uint32_t u; std::memcpy(&u, &v, 4);
+                if ((u & 0x7fffffffu) > 0x7f800000u) return v;                       // NaN: compared as is
+                u += 0x7fffu + ((u >> 16) & 1u); u &= 0xffff0000u;                   // round to nearest even, as the device conversion
+                float r; std::memcpy(&r, &u, 4); return r;
+            };
+            auto elem = [&](const std::vector<unsigned char>& raw, size_t i) {
+                float v;
+                if (h->es == 2) { const uint32_t u = (uint32_t)reinterpret_cast<const uint16_t*>(raw.data())[i] << 16; std::memcpy(&v, &u, 4); }
+                else v = reinterpret_cast<const float*>(raw.data())[i];
+                return v;
+            };
+            float ew = 0.f, et = 0.f;
+            int cnt = 0, worst = -1;
+            auto check = [&](const Dense& d) {
+                if (d.in <= 0 || d.out <= 0) return;
+                std::vector<float> th((size_t)(d.in + 1) * d.ld);
+                std::vector<unsigned char> w((size_t)(d.in + 1) * d.ldw * h->es), wt((size_t)d.out * d.ldt * h->es);
+                HIP_OK(hipMemcpy(th.data(), h->at<float>(h->off_theta) + d.master, th.size() * 4, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(w.data(), h->at<void>(d.W), w.size(), hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(wt.data(), h->at<void>(d.Wt), wt.size(), hipMemcpyDeviceToHost));
+                float a = 0.f, b2 = 0.f;
+                for (int r = 0; r <= d.in; ++r)
+                    for (int c = 0; c < d.out; ++c) {
+                        const float want = round_ct(th[(size_t)r * d.ld + c]);
+                        a = std::max(a, std::fabs(elem(w, (size_t)r * d.ldw + c) - want));
+                        b2 = std::max(b2, std::fabs(elem(wt, (size_t)c * d.ldt + r) - want));
+                    }
+                if (a > ew || b2 > et) worst = cnt;
+                ew = std::max(ew, a); et = std::max(et, b2);
+                ++cnt;
+            };
+            for (const Mod& md : h->mods) {
+                for (const Dense& d : md.enc) check(d);
+                check(md.head);
+                for (const Dense& d : md.dec) check(d);
+                check(md.outl);
+                if (md.conv) { for (const ConvStage& st : md.cenc) check(st.d); for (const ConvStage& st : md.cdec) check(st.d); }
+            }
+            host_dst[0] = ew; host_dst[1] = et; host_dst[2] = (float)cnt; host_dst[3] = (float)worst;
+            if (n_floats) *n_floats = 4;
+            return;
+        }
         else if (n.rfind("mulv", 0) == 0 || n.rfind("g0_", 0) == 0) {
             const bool g0 = n[0] == 'g';
             const int m = std::atoi(n.c_str() + (g0 ? 3 : 4));
