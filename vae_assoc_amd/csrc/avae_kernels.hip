@@ -2489,15 +2489,23 @@ __global__ void __launch_bounds__(kThreads) k_prep(PrepArgs a) {
     const float* src = w.src + (size_t)bstep * w.rows * w.src_ld;
     float* dst32 = w.dst32 ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(w.dst32) + set_off) : nullptr;
     CT* dstc = reinterpret_cast<CT*>(reinterpret_cast<unsigned char*>(w.dstc) + set_off);
+    // the caller's rows as one 16-byte load per quad whatever their alignment (column blocks of a [rows][931] matrix start anywhere)
+    typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // dword-aligned quad: one global_load_dwordx4 (the
+                                                                                  // hardware takes any dword alignment in global memory)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (tid >> 4) + 16 * i;
         const int grow = r0 + r, gcol = c0 + c4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (grow < w.rows && gcol < w.cols) {
+            if (gcol + 3 < w.cols) {
+                const f32x4_a4 q = *reinterpret_cast<const f32x4_a4*>(src + (size_t)grow * w.src_ld + gcol);
+                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (gcol + e < w.cols) v[e] = src[(size_t)grow * w.src_ld + gcol + e];
+                for (int e = 0; e < 4; ++e)
+                    if (gcol + e < w.cols) v[e] = src[(size_t)grow * w.src_ld + gcol + e];
+            }
             const int nv = w.cols - gcol;
             if (dst32) store_row<float>(dst32 + (size_t)grow * w.ld32 + gcol, v, nv);
             store_row<CT>(dstc + (size_t)grow * w.ldc + gcol, v, nv);
