@@ -17,38 +17,49 @@ import numpy as np
 
 
 class DataSets(object):
-    pass
+    """namespace for the three splits: .train, .validation, .test"""
 
 
 class DataSet(object):
+    """Rows (and optional labels) behind a cursor.  The private names ``_data`` and ``_num_examples`` are part of the contract:
+    the reference's ``train()`` reads them (vae_assoc.py:510,543)."""
+
     def __init__(self, data, labels=None):
+        rows = int(data.shape[0])
         if labels is not None:
-            assert data.shape[0] == labels.shape[0], (
-                'data.shape: %s labels.shape: %s' % (data.shape, labels.shape))
-        self._num_examples = data.shape[0]
-        self._data = data
-        self._labels = labels
+            assert int(labels.shape[0]) == rows, "data.shape: %s labels.shape: %s" % (data.shape, labels.shape)
+        self._data, self._labels = data, labels
+        self._num_examples = rows
+        self._index_in_epoch = 0          # cursor: first row of the NEXT batch
         self._epochs_completed = 0
+
+    def _take(self, order):
+        """re-order the rows (and labels) by an index array"""
+        self._data = self._data[order]
+        if self._labels is not None:
+            self._labels = self._labels[order]
+
+    def _wrap(self):
+        """A batch would run past the end: the epoch is over.  ONE ``np.random.shuffle`` of ``arange(N)`` -- the RNG call the reference
+        makes at this point (dataset.py:30-31), so that seeded runs visit the same rows -- then the cursor returns to row 0; whatever
+        was left of the old order is dropped."""
+        order = np.arange(self._num_examples)
+        np.random.shuffle(order)
+        self._take(order)
+        self._epochs_completed += 1
         self._index_in_epoch = 0
 
+    def _slice(self, lo, hi):
+        return self._data[lo:hi], (None if self._labels is None else self._labels[lo:hi])
+
     def next_batch(self, batch_size):
-        """Return the next `batch_size` examples from this data set."""
-        start = self._index_in_epoch
-        self._index_in_epoch += batch_size
-        if self._index_in_epoch > self._num_examples:
-            self._epochs_completed += 1          # finished epoch
-            perm = np.arange(self._num_examples)
-            np.random.shuffle(perm)              # shuffle the data
-            self._data = self._data[perm]
-            if self._labels is not None:
-                self._labels = self._labels[perm]
-            start = 0                            # start next epoch
-            self._index_in_epoch = batch_size
+        """``(data[lo:hi], labels[lo:hi] or None)`` of the next ``batch_size`` rows (dataset.py:22-43)"""
+        if self._index_in_epoch + batch_size > self._num_examples:
+            self._wrap()
             assert batch_size <= self._num_examples
-        end = self._index_in_epoch
-        if self._labels is not None:
-            return self._data[start:end], self._labels[start:end]
-        return self._data[start:end], None
+        lo = self._index_in_epoch
+        self._index_in_epoch = lo + batch_size
+        return self._slice(lo, lo + batch_size)
 
     def next_batches(self, batch_size, max_batches):
         """``n <= max_batches`` successive ``next_batch`` results as ONE contiguous slice of ``n*batch_size``
@@ -56,36 +67,32 @@ class DataSet(object):
         the slices stay consecutive (up to the next wrap).  Returns ``(data, labels, n)``; the state
         afterwards is what ``n`` ``next_batch`` calls leave behind."""
         self.next_batch(batch_size)
-        start = self._index_in_epoch - batch_size
+        lo = self._index_in_epoch - batch_size
         n = 1 + max(0, min(int(max_batches) - 1, (self._num_examples - self._index_in_epoch) // batch_size))
-        self._index_in_epoch = start + n * batch_size
-        end = self._index_in_epoch
-        return self._data[start:end], (self._labels[start:end] if self._labels is not None else None), n
+        self._index_in_epoch = lo + n * batch_size
+        d, l = self._slice(lo, self._index_in_epoch)
+        return d, l, n
 
 
 def construct_datasets(data, labels=None, shuffle=True, validation_ratio=.1, test_ratio=.1):
-    data_sets = DataSets()
+    """Optional shuffle (one ``np.random.shuffle`` of ``arange(N)``), then train | validation | test at
+    ``int((1 - validation_ratio - test_ratio) N)`` and ``int((1 - test_ratio) N)`` (dataset.py:45-72)."""
+    rows = int(data.shape[0])
     if shuffle:
-        perm = np.arange(data.shape[0])
-        np.random.shuffle(perm)
-        data_shuffled = data[perm]
-        labels_shuffled = labels[perm] if labels is not None else None
-    else:
-        data_shuffled = data
-        labels_shuffled = labels
-    n = data_shuffled.shape[0]
-    test_start_idx = int((1 - test_ratio) * n)
-    validation_start_idx = int((1 - validation_ratio - test_ratio) * n)
-    lab = (lambda a, b: labels_shuffled[a:b]) if labels is not None else (lambda a, b: None)
-    data_sets.train = DataSet(data_shuffled[:validation_start_idx, :], lab(0, validation_start_idx))
-    data_sets.validation = DataSet(data_shuffled[validation_start_idx:test_start_idx, :],
-                                   lab(validation_start_idx, test_start_idx))
-    data_sets.test = DataSet(data_shuffled[test_start_idx:, :], lab(test_start_idx, n))
-    return data_sets
+        order = np.arange(rows)
+        np.random.shuffle(order)
+        data = data[order]
+        labels = None if labels is None else labels[order]
+    cut_val, cut_test = int((1 - validation_ratio - test_ratio) * rows), int((1 - test_ratio) * rows)
+    out = DataSets()
+    for name, lo, hi in (("train", 0, cut_val), ("validation", cut_val, cut_test), ("test", cut_test, rows)):
+        setattr(out, name, DataSet(data[lo:hi, :], None if labels is None else labels[lo:hi]))
+    return out
 
 
 class DeviceDataSet(DataSet):
-    """DataSet whose ``_data`` is a torch tensor on the GPU; ``next_batch`` returns device views."""
+    """DataSet whose ``_data`` is a torch tensor on the GPU; ``next_batch`` returns device views.  The permutation still comes from
+    ``np.random.shuffle`` on the host (same stream as the reference); only the gather runs on the device."""
 
     def __init__(self, data, labels=None, device=None):
         import torch
@@ -94,22 +101,11 @@ class DeviceDataSet(DataSet):
         data = data.to(device if device is not None else "cuda", dtype=torch.float32)
         DataSet.__init__(self, data, labels)
 
-    def next_batch(self, batch_size):
+    def _take(self, order):
         import torch
-        start = self._index_in_epoch
-        self._index_in_epoch += batch_size
-        if self._index_in_epoch > self._num_examples:
-            self._epochs_completed += 1
-            perm = np.arange(self._num_examples)
-            np.random.shuffle(perm)                   # same host RNG stream as the reference (dataset.py:30-31)
-            self._data = self._data[torch.as_tensor(perm, device=self._data.device)]
-            if self._labels is not None:
-                self._labels = self._labels[perm]
-            start = 0
-            self._index_in_epoch = batch_size
-            assert batch_size <= self._num_examples
-        end = self._index_in_epoch
-        return self._data[start:end], (self._labels[start:end] if self._labels is not None else None)
+        self._data = self._data[torch.as_tensor(order, device=self._data.device)]
+        if self._labels is not None:
+            self._labels = self._labels[order]
 
 
 def to_device(data_sets, device=None):
