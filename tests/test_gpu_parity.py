@@ -1138,6 +1138,36 @@ def test_concurrent_callers_serialise(V):
     assert not errs, errs
 
 
+@pytest.mark.parametrize("act", ["identity", "relu"])
+def test_back_to_back_steps_equal_synchronised_steps(V, act):
+    """Two single steps submitted back to back, 300 times, against the same two steps with a host synchronisation in between: bitwise.
+    The identity activation is the case that matters: act'(y) = 1 lets the compiler drop the loads of y in the kernels that have the
+    transfer function at compile time, and k_small_latb's counted waits (written for a fixed number of younger loads) then let a K
+    tile be read before it had landed -- about once in 60 steps, found by tools/fuzz_parity.py api as runs that differed from
+    themselves (n_z = 32: the 64-column head tile of the lean tail kernel; fp32)."""
+    archs = [make_arch("image", 784, 500, 500, 32), make_arch("joint", 147, 200, 200, 32)]
+    B, n = 64, 2
+    rng = np.random.default_rng(5)
+    model, _ref = build_pair(V, archs, [True, False], [1.0, 50.0], 0.0, act, B, "fp32", seed=3001)
+    p0 = model.get_params()
+    data = torch.as_tensor(np.concatenate(synth_batch(rng, n * B, [784, 147], [True, False]), axis=1)).cuda()
+    X = [data[:, :784], data[:, 784:]]
+    eps = torch.as_tensor(rng.standard_normal((n * B, 32)).astype(np.float32)).cuda()
+
+    def run(sync):
+        m = V.AssocVariationalAutoEncoder(archs, binary=[True, False], transfer_fct=act, weights=[1.0, 50.0], assoc_lambda=0.0, batch_size=B,
+                                          compute_dtype="fp32", seed=7)
+        m.set_params(p0)
+        for i in range(n):
+            m.partial_fit([x[i * B:(i + 1) * B] for x in X], eps[i * B:(i + 1) * B], return_cost=False)
+            if sync:
+                torch.cuda.synchronize()
+        return m.get_params()
+    truth = run(True)
+    differing = sum(1 for _ in range(300) if not np.array_equal(run(False), truth))
+    assert differing == 0, "%d of 300 back-to-back runs differ from the synchronised run" % differing
+
+
 def test_determinism_and_stress_config_c4(V):
     """BASELINE C4 (4x1024 hidden, n_z=64, B=4096, bf16): too big for the oracle in seconds at full
     batch, so: bitwise run-to-run determinism, finite decreasing cost, and oracle parity of the cost on

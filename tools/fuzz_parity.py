@@ -24,10 +24,17 @@ def main():
     from conftest import make_arch, synth_batch
     from vae_assoc_amd import vae_assoc as V
     rng = np.random.default_rng(seed)
+    only = set(int(x) for x in os.environ["FUZZ_ONLY"].split(",")) if os.environ.get("FUZZ_ONLY") else None
     acts = ["relu", "softplus", "tanh", "sigmoid", "identity"]
     t0, case, bad = time.time(), 0, []
     api_mode = len(sys.argv) > 3 and sys.argv[3] == "api"
     while api_mode and time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, case])       # every case from its own stream: FUZZ_ONLY=<case> reruns one
+        if only is not None and case not in only:
+            case += 1
+            if case > max(only):
+                break
+            continue
         # the rest of the surface on random models (MLP and conv modalities): transform / generate / reconstruct at row counts
         # around batch_size against the oracle; a multi-step run against the same steps one by one, bitwise; save -> restore ->
         # the next steps identical
@@ -116,6 +123,12 @@ def main():
             print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
     dp_mode = len(sys.argv) > 3 and sys.argv[3] == "dp"
     while dp_mode and time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, case])       # every case from its own stream: FUZZ_ONLY=<case> reruns one
+        if only is not None and case not in only:
+            case += 1
+            if case > max(only):
+                break
+            continue
         # the data-parallel contract on random models: R replicas of B rows each (row_offset r*B, batch_global R*B) --
         # their gradients and costs SUM to the single replica's at R*B rows, and after the same reduced gradient is applied the
         # replicas are bitwise equal
@@ -195,6 +208,12 @@ def main():
             print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
     conv_mode = len(sys.argv) > 3 and sys.argv[3] == "conv"
     while conv_mode and time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, case])       # every case from its own stream: FUZZ_ONLY=<case> reruns one
+        if only is not None and case not in only:
+            case += 1
+            if case > max(only):
+                break
+            continue
         # conv / deconv image branches (random depths, 1-3 modalities of which at least one is conv), THREE steps, fp32 and bf16, the
         # default implicit-GEMM policy and every stage implicit / explicit -- each against the oracle (the routes sum in different
         # orders: no bitwise twin here)
@@ -238,6 +257,12 @@ def main():
         if case % 5 == 0:
             print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
     while not conv_mode and not api_mode and not dp_mode and time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, case])       # every case from its own stream: FUZZ_ONLY=<case> reruns one
+        if only is not None and case not in only:
+            case += 1
+            if case > max(only):
+                break
+            continue
         M = int(rng.integers(1, 4))
         nz = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 20, 31, 32, 33, 48, 64]))
         B = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 100, 129, 200, 256, 300]))

@@ -1680,6 +1680,11 @@ __global__ void __launch_bounds__(kThreads) k_small_latb(const LaunchArgs args, 
         buf = buf + 1 == RING ? 0 : buf + 1;
     }
 #undef AVAE_H_DMA
+    // The count of the extra loads has to hold for EVERY transfer function: with the identity, act'(y) = 1 needs no y, the compiler
+    // dropped the two `ty` loads, and the waits above -- written for kExtra younger loads -- let two pieces of the awaited tile stay in
+    // flight: a K tile was read before it had landed about once in 60 steps (tools/fuzz_parity.py api found runs that differed from
+    // themselves).  Naming the registers as inputs of an empty statement HERE (behind the loop: no wait is forced early) keeps the loads.
+    asm volatile("" :: "v"(ty[0]), "v"(ty[1]));
     AVAE_STAMP(3)
     // ---- dz -> (dmu, dlv): into the image (every slice) and into dH (slice 0)
     {
