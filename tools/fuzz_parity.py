@@ -4,7 +4,7 @@ dtype shadows and moments a step leaves behind only show in the next one), plus 
 (AVAE_NO_ADAM_FUSE=1, AVAE_NO_LEAN=1 ...) bitwise.  tests/test_gpu_parity.py::test_random_shapes is the fixed-seed subset that runs
 in the suite; this tool is for spending GPU minutes on shapes nobody thought of.
 
-    python tools/fuzz_parity.py [seconds] [seed] [conv | api | dp]
+    python tools/fuzz_parity.py [seconds] [seed] [conv | api | dp | det]
 """
 import os
 import sys
@@ -120,6 +120,71 @@ def main():
             print("STRUCTURAL" if structural else "tolerance", desc, "\n     ", msg[:400], flush=True)
         case += 1
         if case % 5 == 0:
+            print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
+    det_mode = len(sys.argv) > 3 and sys.argv[3] == "det"
+    while det_mode and time.time() - t0 < budget:
+        # timing races: three single steps submitted back to back, 25 times, against the same steps with a host synchronisation
+        # after each -- bitwise.  (How the identity-activation race of k_small_latb shows: rare, and only without the synchronisation.)
+        rng = np.random.default_rng([seed, case])
+        if only is not None and case not in only:
+            case += 1
+            if case > max(only):
+                break
+            continue
+        import torch
+        M = int(rng.integers(1, 4))
+        nz = int(rng.choice([1, 4, 8, 20, 31, 32, 33, 64]))
+        B = int(rng.choice([8, 32, 64, 100, 128, 160, 256]))
+        dtype = str(rng.choice(["fp32", "bf16"]))
+        archs, binary, w = [], [], []
+        for m in range(M):
+            if rng.integers(0, 5) == 0 and B <= 64:
+                g1, g2 = int(rng.choice([2, 8, 16, 64])), int(rng.integers(1, 21))
+                archs.append(dict(make_arch("c%d" % m, 784, int(rng.integers(1, 25)), int(rng.integers(1, 81)), nz), hidden_conv=True,
+                                  n_hidden_gener_1=g1, n_hidden_gener_2=g2))
+                binary.append(True)
+            else:
+                top = int(rng.choice([64, 300, 600]))
+                hs = [int(rng.integers(1, top + 1)) for _ in range(int(rng.integers(1, 4)))]
+                archs.append(make_arch("m%d" % m, int(rng.integers(1, 801)), 0, 0, nz, n_hidden=hs))
+                binary.append(bool(rng.integers(0, 2)))
+            w.append(float(rng.choice([0.5, 1.0, 50.0])))
+        lam = float(rng.choice([0.0, 0.3, 8.0]))
+        act = acts[case % len(acts)] if not any(a.get("hidden_conv") for a in archs) else "relu"
+        widths = [a["n_input"] for a in archs]
+        desc = "det case %d seed %d: %s M=%d nz=%d B=%d act=%s lam=%g archs=%s binary=%s" % (case, seed, dtype, M, nz, B, act, lam, [
+            (a["n_input"], a.get("n_hidden") or (a.get("n_hidden_recog_1"), a.get("n_hidden_recog_2"), a.get("n_hidden_gener_1"), a.get("n_hidden_gener_2")))
+            for a in archs], binary)
+        try:
+            n = 3
+            model, _ref = T.build_pair(V, archs, binary, w, lam, act, B, dtype, seed=4000 + case)
+            p0 = model.get_params()
+            del model
+            data = torch.as_tensor(np.concatenate(synth_batch(rng, n * B, widths, binary), axis=1)).cuda()
+            cols = np.cumsum([0] + widths)
+            Xd = [data[:, cols[m]:cols[m + 1]] for m in range(M)]
+            eps = torch.as_tensor(rng.standard_normal((n * B, nz)).astype(np.float32)).cuda()
+
+            def run(sync):
+                mm = V.AssocVariationalAutoEncoder(archs, binary=binary, transfer_fct=act, weights=w, assoc_lambda=lam, batch_size=B,
+                                                   compute_dtype=dtype, seed=7)
+                mm.set_params(p0)
+                for i in range(n):
+                    mm.partial_fit([x[i * B:(i + 1) * B] for x in Xd], eps[i * B:(i + 1) * B], return_cost=False)
+                    if sync:
+                        torch.cuda.synchronize()
+                return mm.get_params()
+            truth = run(True)
+            differing = sum(1 for _ in range(25) if not np.array_equal(run(False), truth, equal_nan=True))
+            if differing:
+                raise AssertionError("default plan vs itself: %d of 25 back-to-back runs differ from the synchronised run" % differing)
+        except Exception as e:
+            msg = repr(e)
+            structural = not isinstance(e, AssertionError) or "default plan vs" in msg
+            bad.append((desc, msg[:400], structural))
+            print("STRUCTURAL" if structural else "tolerance", desc, "\n     ", msg[:400], flush=True)
+        case += 1
+        if case % 10 == 0:
             print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
     dp_mode = len(sys.argv) > 3 and sys.argv[3] == "dp"
     while dp_mode and time.time() - t0 < budget:
@@ -256,7 +321,7 @@ def main():
         case += 1
         if case % 5 == 0:
             print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
-    while not conv_mode and not api_mode and not dp_mode and time.time() - t0 < budget:
+    while not conv_mode and not api_mode and not dp_mode and not det_mode and time.time() - t0 < budget:
         rng = np.random.default_rng([seed, case])       # every case from its own stream: FUZZ_ONLY=<case> reruns one
         if only is not None and case not in only:
             case += 1
