@@ -136,9 +136,16 @@ def main():
         nz = int(rng.choice([1, 4, 8, 20, 31, 32, 33, 64]))
         B = int(rng.choice([8, 32, 64, 100, 128, 160, 256]))
         dtype = str(rng.choice(["fp32", "bf16"]))
+        big = os.environ.get("FUZZ_BIG") == "1"          # the 8-wave tile paths: big batches, wide layers
+        if big:
+            B, M = int(rng.choice([1024, 2048, 4096])), int(rng.integers(1, 3))
         archs, binary, w = [], [], []
         for m in range(M):
-            if rng.integers(0, 5) == 0 and B <= 64:
+            if big:
+                hs = [int(rng.choice([512, 768, 1000, 1024])) for _ in range(int(rng.integers(1, 4)))]
+                archs.append(make_arch("m%d" % m, int(rng.choice([147, 500, 784])), 0, 0, nz, n_hidden=hs))
+                binary.append(bool(rng.integers(0, 2)))
+            elif rng.integers(0, 5) == 0 and B <= 64:
                 g1, g2 = int(rng.choice([2, 8, 16, 64])), int(rng.integers(1, 21))
                 archs.append(dict(make_arch("c%d" % m, 784, int(rng.integers(1, 25)), int(rng.integers(1, 81)), nz), hidden_conv=True,
                                   n_hidden_gener_1=g1, n_hidden_gener_2=g2))
@@ -332,10 +339,15 @@ def main():
         nz = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 20, 31, 32, 33, 48, 64]))
         B = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 100, 129, 200, 256, 300]))
         dtype = str(rng.choice(["fp32", "bf16"]))
+        big = os.environ.get("FUZZ_BIG") == "1"          # the 8-wave tile paths: big batches, wide layers (the oracle takes seconds per step)
+        if big:
+            B, M = int(rng.choice([1024, 1536, 2048])), int(rng.integers(1, 3))
         archs, binary, w = [], [], []
         for m in range(M):
             top = int(rng.choice([40, 150, 600]))
             hs = [int(rng.integers(1, top + 1)) for _ in range(int(rng.integers(1, 4)))]
+            if big:
+                hs = [int(rng.choice([512, 700, 1000, 1024])) for _ in range(int(rng.integers(1, 3)))]
             archs.append(make_arch("m%d" % m, int(rng.integers(1, 801)), 0, 0, nz, n_hidden=hs))
             binary.append(bool(rng.integers(0, 2)))
             w.append(float(rng.choice([0.5, 1.0, 3.0, 50.0])))
