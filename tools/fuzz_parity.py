@@ -4,7 +4,7 @@ dtype shadows and moments a step leaves behind only show in the next one), plus 
 (AVAE_NO_ADAM_FUSE=1, AVAE_NO_LEAN=1 ...) bitwise.  tests/test_gpu_parity.py::test_random_shapes is the fixed-seed subset that runs
 in the suite; this tool is for spending GPU minutes on shapes nobody thought of.
 
-    python tools/fuzz_parity.py [seconds] [seed] [conv | api | dp | det]
+    python tools/fuzz_parity.py [seconds] [seed] [conv | api | dp | det | train]
 """
 import os
 import sys
@@ -120,6 +120,83 @@ def main():
             print("STRUCTURAL" if structural else "tolerance", desc, "\n     ", msg[:400], flush=True)
         case += 1
         if case % 5 == 0:
+            print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
+    train_mode = len(sys.argv) > 3 and sys.argv[3] == "train"
+    while train_mode and time.time() - t0 < budget:
+        # train() (vae_assoc.py:498-583) on random data-set sizes, batch sizes and epoch counts: the same batch order and explicit eps
+        # through the HIP class (host batches and the device-resident data set) and through the oracle's loop => the same cost history
+        rng = np.random.default_rng([seed, case])
+        if only is not None and case not in only:
+            case += 1
+            if case > max(only):
+                break
+            continue
+        from oracle import vae_assoc_oracle as O
+        from vae_assoc_amd import dataset
+        nz = int(rng.choice([1, 4, 8, 20]))
+        B = int(rng.choice([1, 3, 16, 20, 32, 64, 100]))
+        N = int(rng.integers(max(2 * B, int(B / 0.8) + 2), 40 * B + 50))
+        epochs = int(rng.integers(1, 4))
+        archs = [make_arch("image", int(rng.integers(5, 200)), int(rng.integers(2, 40)), int(rng.integers(2, 40)), nz),
+                 make_arch("joint", int(rng.integers(3, 60)), int(rng.integers(2, 30)), int(rng.integers(2, 30)), nz)]
+        widths = [a["n_input"] for a in archs]
+        binary = [True, bool(rng.integers(0, 2))]
+        w, lam = [float(rng.choice([1.0, 50.0])), 1.0], float(rng.choice([0.0, 1e-5, 8.0]))
+        desc = "train case %d seed %d: N=%d B=%d epochs=%d nz=%d archs=%s binary=%s" % (case, seed, N, B, epochs, nz, [
+            (a["n_input"], a["n_hidden_recog_1"], a["n_hidden_recog_2"]) for a in archs], binary)
+        try:
+            data = np.concatenate(synth_batch(rng, N, widths, binary), axis=1)
+            n_train = int(0.8 * N)
+            steps = epochs * (n_train // B) + 4
+            eps_all = rng.standard_normal((steps, B, nz)).astype(np.float32)
+            hists = []
+            for which in ("host", "device", "oracle"):
+                np.random.seed(1234 + case)
+                ds = dataset.construct_datasets(data.copy())
+                if which == "device":
+                    ds = dataset.to_device(ds)
+                if which != "oracle":
+                    class Fed(V.AssocVariationalAutoEncoder):
+                        _k = 0
+
+                        def partial_fit(self, X, eps=None, return_cost=True):
+                            e = eps_all[Fed._k]
+                            Fed._k += 1
+                            return super().partial_fit(X, e, return_cost)
+
+                        def partial_fit_steps(self, X, n_steps, eps=None, return_cost=True):
+                            e = np.concatenate(eps_all[Fed._k:Fed._k + n_steps])
+                            Fed._k += n_steps
+                            return super().partial_fit_steps(X, n_steps, e, return_cost)
+                    orig = V.AssocVariationalAutoEncoder
+                    V.AssocVariationalAutoEncoder = Fed
+                    try:
+                        model, hist = V.train(ds, archs, binary=binary, weights=w, assoc_lambda=lam, batch_size=B, training_epochs=epochs,
+                                              display_step=1000, compute_dtype="fp32", seed=8)
+                    finally:
+                        V.AssocVariationalAutoEncoder = orig
+                else:
+                    p_init = V.AssocVariationalAutoEncoder(archs, binary=binary, transfer_fct="relu", batch_size=B, compute_dtype="fp32", seed=8).get_params()
+                    model, hist = O.train(ds, archs, binary=binary, weights=w, assoc_lambda=lam, batch_size=B, training_epochs=epochs,
+                                          params_flat=p_init.astype(np.float64), eps_fn=lambda sidx: eps_all[sidx])
+                hists.append((np.asarray(hist, dtype=np.float64), model.get_params()))
+            if len(hists[0][0]) != len(hists[2][0]) or len(hists[1][0]) != len(hists[2][0]):
+                raise AssertionError("default plan vs oracle loop: %d / %d / %d costs recorded" % (len(hists[0][0]), len(hists[1][0]), len(hists[2][0])))
+            if not (np.array_equal(hists[0][0], hists[1][0]) and np.array_equal(hists[0][1], hists[1][1])):
+                raise AssertionError("default plan vs device-resident data set: cost histories differ")
+            err = float(np.max(np.abs(hists[0][0] - hists[2][0]) / np.maximum(np.abs(hists[2][0]), 1e-30))) if len(hists[2][0]) else 0.0
+            if not err <= 2e-4:
+                raise AssertionError("cost history vs the oracle loop: rel err %.3e" % err)
+            if os.environ.get("FUZZ_VERBOSE"):
+                print("ok", desc, "history of %d epochs-costs, max rel err %.2e" % (len(hists[2][0]), err), flush=True)
+        except Exception as e:
+            msg = repr(e)
+            big = "rel err" in msg and float(msg.split("rel err ")[1].rstrip("')\"")) > 0.05
+            structural = not isinstance(e, AssertionError) or "default plan vs" in msg or big
+            bad.append((desc, msg[:400], structural))
+            print("STRUCTURAL" if structural else "tolerance", desc, "\n     ", msg[:400], flush=True)
+        case += 1
+        if case % 10 == 0:
             print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
     det_mode = len(sys.argv) > 3 and sys.argv[3] == "det"
     while det_mode and time.time() - t0 < budget:
@@ -328,7 +405,7 @@ def main():
         case += 1
         if case % 5 == 0:
             print("%d cases, %d beyond a tolerance or failed, %.0f s" % (case, len(bad), time.time() - t0), flush=True)
-    while not conv_mode and not api_mode and not dp_mode and not det_mode and time.time() - t0 < budget:
+    while not conv_mode and not api_mode and not dp_mode and not det_mode and not train_mode and time.time() - t0 < budget:
         rng = np.random.default_rng([seed, case])       # every case from its own stream: FUZZ_ONLY=<case> reruns one
         if only is not None and case not in only:
             case += 1
